@@ -1,0 +1,103 @@
+/*
+ * tfqmrgpu_ext.h -- additive extensions of the MI355X build of libtfQMRgpu.so.
+ *
+ * Nothing in here exists in the reference (real-space/tfQMRgpu); existing callers never
+ * need it.  It adds (1) read-only views for parity tests, (2) control over the shadow
+ * vector v3 so that iteration counts can be compared with the reference CPU path,
+ * (3) a stand-alone BSR multiply on device-resident data (what the reference times in
+ * `bench_tfqmrgpu multi`, bench_tfqmrgpu.cu:289-440) and (4) the multi-GPU mode: right
+ * hand side block columns sharded over ranks, one tiny RCCL all-reduce per stopping test.
+ */
+#ifndef TFQMRGPU_EXT_H
+#define TFQMRGPU_EXT_H
+
+#include "tfqmrgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- (1) plan introspection ------------------------------------------------------------ */
+/* The arrays are exactly the analysis results of the reference createPlan
+ * (tfqmrgpu.cu:183-339, members of bsrsv_plan_t, tfqmrgpu_plan.hxx:21-49): same order,
+ * same integer types, 0-based.  Pointers stay valid until destroyPlan. */
+typedef struct {
+    uint32_t nRows;                        /* mb                                            */
+    uint32_t nCols;                        /* non-empty block columns of X                  */
+    uint32_t nnzbA, nnzbX, nnzbB;
+    uint64_t nPairs;                       /* block products in Y = A*X                     */
+    uint32_t const *pairs;                 /* [2*nPairs]  (inzA, inzX)                      */
+    uint32_t const *starts;                /* [nnzbX + 1] first pair of each Y block        */
+    uint32_t const *subset;                /* [nnzbB]     X block that holds each B block   */
+    uint16_t const *colindx;               /* [nnzbX]     compressed block column           */
+    int32_t  const *original_bsrColIndX;   /* [nCols]     user column index per compressed  */
+    int32_t  LM, LN;                       /* block shape, 0 before bufferSize              */
+    char     precision;                    /* 'c' / 'z', 0 before bufferSize                */
+} tfqmrgpuPlanView_t;
+
+tfqmrgpuStatus_t tfqmrgpuExt_planView(tfqmrgpuBsrsvPlan_t plan, tfqmrgpuPlanView_t *view);
+
+/* per-iteration trace of the last solve: bound2[it] = max_rhs(tau*invBn2)*(2*it+1) as the
+ * stopping test saw it (reference tfqmrgpu_core.hxx:239-252).  Returns how many entries
+ * exist; copies at most `capacity`. */
+int32_t tfqmrgpuExt_getBoundHistory(tfqmrgpuBsrsvPlan_t plan, double *bound2, int32_t capacity);
+
+/* ---- (2) shadow vector v3 -------------------------------------------------------------- */
+enum {
+    TFQMRGPU_SHADOW_HASH       = 0, /* default: counter-based hash of (block row, block column,
+                                       element), uniform (0,1]; independent of the GPU count  */
+    TFQMRGPU_SHADOW_GLIBC_RAND = 1  /* the sequence the reference CPU path uses: glibc rand()
+                                       from seed 1, /RAND_MAX, flat over [nnzbX][2][LM][LN]
+                                       (tfqmrgpu_linalg.hxx:799-802)                          */
+};
+/* call after createPlan and before setBuffer */
+tfqmrgpuStatus_t tfqmrgpuExt_setShadowMode(tfqmrgpuBsrsvPlan_t plan, int mode);
+/* user-supplied v3, host array float[nnzbX][2][LM][LN] in the caller's BSR order; call after setBuffer */
+tfqmrgpuStatus_t tfqmrgpuExt_setShadowVector(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, float const *v3);
+
+/* ---- (3) stand-alone block-sparse multiply --------------------------------------------- */
+/* Y[iY] = sum over pairs p in [starts[iY], starts[iY+1]) of A[pairs[2p]] * X[pairs[2p+1]]
+ * All pointers are DEVICE pointers.  Blocks are in the native layout RRRRIIII:
+ * A[nnzbA][2][lm(k)][lm(i)] (transposed), X|Y[nnzb][2][lm][ln].
+ * Same contract as the reference kernel gemmNxNf (tfqmrgpu_blockmult.hxx:9-93). */
+tfqmrgpuStatus_t tfqmrgpuExt_multiply(tfqmrgpuHandle_t handle,
+    char precision, int lm, int ln,
+    uint32_t nnzbY, uint32_t const *starts_d, uint32_t const *pairs_d,
+    void const *A_d, void const *X_d, void *Y_d);
+
+/* ---- (4) multi-GPU: one process per GPU, block columns of X/B sharded ------------------- */
+/* Splits the compressed block columns of X into `nranks` contiguous ranges with balanced
+ * block counts and extracts the sub-patterns of X and B that belong to `rank`.
+ * Outputs are malloc'ed by the library; release with tfqmrgpuExt_freeShard.
+ * xBlocks/bBlocks list, for every block of the shard, its index in the unsharded operator
+ * (so that values can be scattered/gathered).  Index arrays are 0-based regardless of
+ * indexOffset of the input. */
+typedef struct {
+    int32_t  mb;
+    int32_t  nnzbX, nnzbB;
+    int32_t *rowPtrX, *colIndX;  /* [mb+1], [nnzbX] */
+    int32_t *rowPtrB, *colIndB;  /* [mb+1], [nnzbB] */
+    int32_t *xBlocks, *bBlocks;  /* [nnzbX], [nnzbB] indices into the global value arrays   */
+    int32_t  firstCol, nCols;    /* range of compressed block columns owned by this rank     */
+} tfqmrgpuShard_t;
+
+tfqmrgpuStatus_t tfqmrgpuExt_shardColumns(int mb,
+    int32_t const *rowPtrX, int nnzbX, int32_t const *colIndX,
+    int32_t const *rowPtrB, int nnzbB, int32_t const *colIndB,
+    int indexOffset, int nranks, int rank, tfqmrgpuShard_t *shard);
+void tfqmrgpuExt_freeShard(tfqmrgpuShard_t *shard);
+
+/* RCCL communicator for the stopping test.  rank 0 creates the id, the caller broadcasts the
+ * 128 bytes by any means (torch.distributed, MPI, a file), every rank calls commInit. */
+tfqmrgpuStatus_t tfqmrgpuExt_commUniqueId(char id[128]);
+tfqmrgpuStatus_t tfqmrgpuExt_commInit(tfqmrgpuHandle_t handle, int nranks, int rank, char const id[128]);
+tfqmrgpuStatus_t tfqmrgpuExt_commDestroy(tfqmrgpuHandle_t handle);
+/* Instead of RCCL: a host callback that max-reduces `n` doubles in place over all ranks
+ * (used by the CPU/gloo tests of the sharding logic and by MPI-based callers). */
+typedef void (*tfqmrgpuReduceMax_t)(void *ctx, double *values, int n);
+tfqmrgpuStatus_t tfqmrgpuExt_setReduceCallback(tfqmrgpuHandle_t handle, tfqmrgpuReduceMax_t fn, void *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFQMRGPU_EXT_H */

@@ -1,0 +1,180 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol of include/*.h, and its
+host logic (createPlan index analysis, status codes, block-size table, column sharding) is
+bit-identical with the reference.  No device kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import tfqmrgpu_amd as T
+from conftest import ALL_NAMES, ROOT, load_golden, load_problem, offset1
+from tfqmrgpu_amd import problems as PR
+
+PLAN_KEYS = ("pairs", "starts", "subset", "colindx")
+
+
+def test_every_declared_symbol_is_exported():
+    declared = set()
+    for h in ("tfqmrgpu.h", "tfqmrgpu_ext.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b(tfqmrgpu\w*)\s*\(", text))
+    assert set(T.EXPORTED_SYMBOLS) <= declared and set(T.EXT_SYMBOLS) <= declared
+    for name in sorted(declared) + T.FORTRAN_SYMBOLS:
+        assert hasattr(T.lib, name), name
+    assert len(T.EXPORTED_SYMBOLS) == 21 and len(T.FORTRAN_SYMBOLS) == 18
+
+
+@pytest.mark.parametrize("name", ALL_NAMES)
+def test_create_plan_bit_exact(name):
+    pr, g = load_problem(name), load_golden(name)
+    for p, origkey in ((pr, "plan_original_bsrColIndX"), (offset1(pr), "plan_original_bsrColIndX_off1")):
+        with T.Solver() as s:
+            assert s.create_plan(p) == 0
+            v = s.plan_view()
+        assert v["nCols"] == int(g["plan_nCols"]) and v["nPairs"] == len(g["plan_pairs"]) // 2
+        for k in PLAN_KEYS:
+            assert v[k].dtype == g["plan_" + k].dtype and np.array_equal(v[k], g["plan_" + k]), k
+        assert np.array_equal(v["original_bsrColIndX"], g[origkey])
+
+
+def test_unsorted_and_duplicate_columns_first_match_wins(oracle):
+    # the reference searches linearly and takes the first hit (bsr.hxx:27-39)
+    rng = np.random.default_rng(5)
+    mb = 9
+    rpA, ciA, rpX, ciX = [0], [], [0], []
+    for r in range(mb):
+        ciA += list(rng.permutation(mb)[: rng.integers(1, 5)])
+        rpA.append(len(ciA))
+        cols = list(rng.permutation(7)[: rng.integers(1, 5)] * 3 + 2)
+        if r % 4 == 0:
+            cols.append(cols[0])  # a duplicate entry in the row
+        ciX += cols
+        rpX.append(len(ciX))
+    rpB, ciB = [0], []
+    for r in range(mb):  # B: every (row, column) of X once
+        ciB += list(dict.fromkeys(ciX[rpX[r]:rpX[r + 1]]))
+        rpB.append(len(ciB))
+    A = np.zeros((len(ciA), 4, 4), complex)
+    B = np.zeros((len(ciB), 4, 4), complex)
+    pr = T.Problem(rpA, ciA, A, rpX, ciX, rpB, ciB, B)
+    an = oracle.analyse(pr)
+    with T.Solver() as s:
+        st = T.lib.tfqmrgpu_bsrsv_createPlan(s.handle, C.byref(s.plan), pr.mb, T._ptr(pr.rowPtrA), pr.nnzbA, T._ptr(pr.colIndA),
+                                             T._ptr(pr.rowPtrX), pr.nnzbX, T._ptr(pr.colIndX), T._ptr(pr.rowPtrB), pr.nnzbB,
+                                             T._ptr(pr.colIndB), 0, 0)
+        assert st == 0 and an["status"] == 0
+        v = s.plan_view()
+        for k in PLAN_KEYS + ("original_bsrColIndX",):
+            assert np.array_equal(v[k], an[k]), k
+    # two blocks of B on one block of X: the reference accepts it, the GPU build refuses (code 19)
+    dup = T.Problem(rpA, ciA, A, rpX, ciX, rpX, ciX, np.zeros((len(ciX), 4, 4), complex))
+    assert oracle.analyse(dup)["status"] == 0
+    with T.Solver() as s:
+        assert T.decode(_create(dup, s.handle, s.plan))[0] == 19
+
+
+def _create(pr, handle, plan):
+    return T.lib.tfqmrgpu_bsrsv_createPlan(handle, C.byref(plan), pr.mb, T._ptr(pr.rowPtrA), pr.nnzbA, T._ptr(pr.colIndA),
+                                           T._ptr(pr.rowPtrX), pr.nnzbX, T._ptr(pr.colIndX), T._ptr(pr.rowPtrB), pr.nnzbB,
+                                           T._ptr(pr.colIndB), pr.index_offset, 0)
+
+
+def test_create_plan_status_codes(oracle):
+    pr = PR.stencil_2d(4, 3, 4, 4, 3, seed=9)
+    s = T.Solver()
+    # B block outside the pattern of X: code 13, the block row travels in the line field (tfqmrgpu.cu:245)
+    bad = T.Problem(pr.rowPtrA, pr.colIndA, pr.A, pr.rowPtrX, pr.colIndX, pr.rowPtrB, pr.colIndB + 5, pr.B)
+    st = _create(bad, s.handle, s.plan)
+    row = int(np.nonzero(np.diff(pr.rowPtrB))[0][0])
+    assert st == 13 + 1000 * row and not s.plan
+    assert oracle.analyse(bad)["status"] == st
+    assert "row %d" % row in T.error_string(st)
+    # a column of X without any block of B: code 11, the count travels in the line field (tfqmrgpu.cu:335)
+    keep = pr.colIndB != 1
+    rpB = np.concatenate([[0], np.cumsum([np.sum(keep[pr.rowPtrB[r]:pr.rowPtrB[r + 1]]) for r in range(pr.mb)])])
+    nob = T.Problem(pr.rowPtrA, pr.colIndA, pr.A, pr.rowPtrX, pr.colIndX, rpB, pr.colIndB[keep], pr.B[keep])
+    st = _create(nob, s.handle, s.plan)
+    assert st == 11 + 1000 * 1 and oracle.analyse(nob)["status"] == st
+    # inconsistent nnzb: code 14
+    st = T.lib.tfqmrgpu_bsrsv_createPlan(s.handle, C.byref(s.plan), pr.mb, T._ptr(pr.rowPtrA), pr.nnzbA + 1, T._ptr(pr.colIndA),
+                                         T._ptr(pr.rowPtrX), pr.nnzbX, T._ptr(pr.colIndX), T._ptr(pr.rowPtrB), pr.nnzbB,
+                                         T._ptr(pr.colIndB), 0, 0)
+    assert T.decode(st)[0] == 14
+    # *plan must be NULL on entry: code 7 (tfqmrgpu.cu:161)
+    assert s.create_plan(pr) == 0
+    assert T.decode(_create(pr, s.handle, s.plan))[0] == 7
+    # getInfo with nothing to fill: 3 (tfqmrgpu.cu:678); bufferSize argument checks (tfqmrgpu.cu:377-379)
+    assert T.lib.tfqmrgpu_bsrsv_getInfo(s.handle, s.plan, None, None, None, None) == 3
+    n = C.c_size_t(0)
+    assert T.decode(T.lib.tfqmrgpu_bsrsv_bufferSize(s.handle, s.plan, 4, 8, 4, 4, b"z", C.byref(n)))[0] == 14
+    assert T.decode(T.lib.tfqmrgpu_bsrsv_bufferSize(s.handle, s.plan, 8, 8, 4, 4, b"z", C.byref(n)))[0] == 14
+    st = T.lib.tfqmrgpu_bsrsv_bufferSize(s.handle, s.plan, 6, 6, 6, 6, b"z", C.byref(n))
+    assert T.decode(st) == (12, 6, 6)  # missing block size: char = LM, line = LN (tfqmrgpu.cu:70)
+    assert T.lib.tfqmrgpu_bsrsv_bufferSize(s.handle, s.plan, 4, 4, 4, 4, b"z", C.byref(n)) == 0 and n.value > 0
+    nz = n.value
+    assert T.lib.tfqmrgpu_bsrsv_bufferSize(s.handle, s.plan, 4, 4, 4, 4, b"f", C.byref(n)) == 0 and n.value < nz
+    # setBuffer(NULL): 7; getBuffer before setBuffer: 7
+    assert T.decode(T.lib.tfqmrgpu_bsrsv_setBuffer(s.handle, s.plan, None))[0] == 7
+    p = C.c_void_p(None)
+    assert T.decode(T.lib.tfqmrgpu_bsrsv_getBuffer(s.handle, s.plan, C.byref(p)))[0] == 7
+    # argument decoding of setMatrix happens before any device work (tfqmrgpu.cu:481-533)
+    a = np.zeros(8)
+    assert T.decode(T.lib.tfqmrgpu_bsrsv_setMatrix(s.handle, s.plan, b"A", T._ptr(a), b"z", 4, 4, b"n", 0x77)) == (15, 0x77, 0)
+    assert T.decode(T.lib.tfqmrgpu_bsrsv_setMatrix(s.handle, s.plan, b"A", T._ptr(a), b"z", 4, 4, b"q", 0x55))[::2] == (17, ord("q"))
+    assert T.decode(T.lib.tfqmrgpu_bsrsv_setMatrix(s.handle, s.plan, b"Q", T._ptr(a), b"z", 4, 4, b"n", 0x55))[::2] == (18, ord("Q"))
+    assert T.decode(T.lib.tfqmrgpu_bsrsv_getMatrix(s.handle, s.plan, b"A", T._ptr(a), b"z", 4, 4, b"n", 0x55))[::2] == (14, ord("A"))
+    s.close()
+    h = C.c_void_p(1)
+    assert T.decode(T.lib.tfqmrgpuCreateHandle(C.byref(h)))[0] == 14  # handle must be NULL on entry
+
+
+def test_allowed_block_sizes_like_the_reference():
+    want = [(4, 4), (4, 5), (4, 8), (4, 32), (8, 8), (8, 9), (8, 10), (8, 32), (8, 64),
+            (16, 16), (16, 32), (16, 64), (32, 32), (32, 64), (64, 64)]  # allowed_block_sizes.h:4-18
+    n = C.c_int32(0)
+    arr = (C.c_int32 * 200)(*([7] * 200))
+    assert T.lib.tfqmrgpu_bsrsv_allowedBlockSizes(C.byref(n), arr, 200) == 0
+    assert n.value == 15 and [(arr[2 * i], arr[2 * i + 1]) for i in range(15)] == want
+    assert arr[30] == 7  # the array is only cleared when *number != 0 on entry (tfqmrgpu.cu:83)
+    n = C.c_int32(1)
+    assert T.lib.tfqmrgpu_bsrsv_allowedBlockSizes(C.byref(n), arr, 200) == 0 and arr[30] == 0
+    small = (C.c_int32 * 8)()
+    n = C.c_int32(0)
+    st = T.lib.tfqmrgpu_bsrsv_allowedBlockSizes(C.byref(n), small, 8)  # pairs stored while 2*n < arrayLength
+    assert n.value == 15 and T.decode(st)[0] == 14 and list(small)[:6] == [4, 4, 4, 5, 4, 8]
+    for lm, ln in want:
+        assert T.lib.tfqmrgpu_bsrsv_blockSizeMissing(lm, ln) == 0
+    assert T.decode(T.lib.tfqmrgpu_bsrsv_blockSizeMissing(3, 5)) == (12, 5, 3)
+
+
+def test_error_strings():
+    assert T.error_string(0) == ""
+    assert T.error_string(9) == "tfQMRgpu: Max number of iterations exceeded!"
+    assert T.error_string(6) == "tfQMRgpu: All components have broken down!"
+    assert T.error_string(12 + 1000 * 64 + 10000000 * 16) == "tfQMRgpu: Missing blocksize 16 x 64!"
+    assert T.error_string(17 + 1000 * 498 + 10000000 * ord("q")) == "tfQMRgpu: Unknown transposition 'q' at line 498!"
+    assert T.error_string(15 + 1000 * 0x77) == "tfQMRgpu: Unknown data layout '0x77'!"
+    assert T.error_string(11 + 1000 * 3) == "tfQMRgpu: B has 3 zero columns, will break!"
+
+
+def test_shard_columns_partition():
+    pr = PR.stencil_2d(6, 6, 4, 4, 7, seed=2, radius=2.2)
+    cols = np.unique(pr.colIndX)
+    for nranks in (1, 2, 3, 7):
+        seen_x, seen_b, first = [], [], 0
+        for rank in range(nranks):
+            sub, xb, bb = T.shard_columns(pr, nranks, rank)
+            assert sub.first_col == first and sub.n_cols >= 1
+            first += sub.n_cols
+            mine = cols[sub.first_col: sub.first_col + sub.n_cols]
+            assert np.array_equal(np.unique(sub.colIndX), mine)
+            assert np.array_equal(pr.colIndX[xb], sub.colIndX) and np.array_equal(pr.colIndB[bb], sub.colIndB)
+            rows = np.repeat(np.arange(pr.mb), np.diff(pr.rowPtrX))
+            assert np.array_equal(rows[xb], np.repeat(np.arange(pr.mb), np.diff(sub.rowPtrX)))
+            seen_x += list(xb)
+            seen_b += list(bb)
+        assert first == len(cols)
+        assert sorted(seen_x) == list(range(pr.nnzbX)) and sorted(seen_b) == list(range(pr.nnzbB))

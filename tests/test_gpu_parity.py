@@ -1,0 +1,314 @@
+"""Parity of the HIP path (through the C-ABI of libtfQMRgpu.so) with the CPU oracle and the golden
+vectors of the reference.  Needs an MI355X: run with `pytest -m gpu`.
+
+Tolerances: integer results bit-exact; complex<double> solutions within
+1e-7*max|X| at threshold 1e-9, complex<float> within 1e-3*max|X|; reported residual within 1e-6
+relative and equal iteration counts when both sides use the same shadow vector (glibc mode)."""
+import ctypes as C
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import tfqmrgpu_amd as T
+from conftest import ALL_NAMES, GOLDEN, golden_solves, load_golden, load_problem
+from tfqmrgpu_amd import problems as PR
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(4, 4), (4, 5), (4, 8), (4, 32), (8, 8), (8, 9), (8, 10), (8, 32), (8, 64),
+         (16, 16), (16, 32), (16, 64), (32, 32), (32, 64), (64, 64)]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "the gpu tests need a GPU; there is no CPU fallback"
+    torch.cuda.set_device(0)
+    return torch
+
+
+def _tol(prec):
+    return 1e-7 if prec == "z" else 1e-3
+
+
+@pytest.mark.parametrize("name", ALL_NAMES)
+def test_solve_matches_oracle_and_golden(oracle, name):
+    pr, g = load_problem(name), load_golden(name)
+    for prec, tol, maxit in golden_solves(g):
+        tag = "solve_%s_" % prec
+        st, X, info = T.solve_problem(pr, prec, threshold=tol, max_iterations=maxit, shadow_mode=T.SHADOW_GLIBC_RAND)
+        st0, X0, info0 = oracle.solve(pr, prec, threshold=tol, max_iterations=maxit)
+        assert st == st0 == int(g[tag + "status"])
+        if st != 0:
+            continue  # a run into maxIterations (float floor) has no meaningful solution to compare
+        scale = float(g[tag + "maxabsX"])
+        assert np.abs(X - X0).max() <= _tol(prec) * scale, (name, prec)
+        if tag + "X" in g:
+            assert np.abs(X - g[tag + "X"]).max() <= _tol(prec) * scale
+        else:
+            assert np.abs(X.reshape(-1)[::97] - g[tag + "X_sample"]).max() <= _tol(prec) * scale
+        if prec == "z":
+            assert info["iterations"] == info0["iterations"] == int(g[tag + "iterations"])
+            assert info["flops"] == float(g[tag + "flops"])
+            assert info["residual"] == pytest.approx(info0["residual"], rel=1e-6)
+            h, h0 = info["bound_history"], info0["bound_history"]
+            assert len(h) == len(h0) and np.allclose(h, h0, rtol=1e-6, atol=0)
+        else:
+            assert abs(info["iterations"] - info0["iterations"]) <= 2
+            assert info["residual"] <= tol
+
+
+@pytest.mark.parametrize("name", ["fd_16x16_small", "fd_8x8_3d", "dense_random", "julia_kat"])
+def test_default_shadow_vector_converges_to_the_same_solution(oracle, name):
+    pr = load_problem(name)
+    tol = {"julia_kat": 1.2e-8, "dense_random": 1e-10}.get(name, pr.tolerance)
+    st, X, info = T.solve_problem(pr, "z", threshold=tol, max_iterations=500)
+    st0, X0, info0 = oracle.solve(pr, "z", threshold=tol, max_iterations=500)
+    assert st == st0 == 0
+    assert abs(info["iterations"] - info0["iterations"]) <= 3
+    assert info["residual"] <= tol
+    assert np.abs(X - X0).max() <= 1e-6 * np.abs(X0).max()
+
+
+def test_known_answers():
+    pr = PR.julia_kat()  # example/tfqmrgpu_Julia_example.jl:117-120
+    st, X, info = T.solve_problem(pr, "z", threshold=1.2e-8, max_iterations=210)
+    assert st == 0
+    line = np.arange(1, 8) / 8.0
+    for j in range(5):
+        assert np.abs(X[:, j % 4, j] - line * 1j ** (j // 4)).max() < 1e-9
+    st, X, info = T.solve_problem(pr, "c", threshold=1.2e-5, max_iterations=210)
+    assert st == 0 and np.abs(X[:, 0, 0] - line).max() < 1e-4
+    pr = PR.dense_random()  # example/tfqmrgpu_Fortran_example.F90:108-126: A*X == B, A not symmetric
+    Xd = PR.dense_reference_solution(pr)
+    st, X, info = T.solve_problem(pr, "z", threshold=1e-10, max_iterations=500)
+    assert st == 0 and np.abs(X - Xd).max() < 1e-8 * np.abs(Xd).max()
+
+
+@pytest.mark.parametrize("trans", ["n", "t", "c", "h", "*", "N", "T"])
+def test_trans_flags_of_A(trans):
+    pr = PR.dense_random(mb=4, LM=8, LN=8, ncols=2, seed=31)
+    op = {"n": lambda a: a, "t": lambda a: a.transpose(0, 2, 1), "c": lambda a: a.conj().transpose(0, 2, 1),
+          "h": lambda a: a.conj().transpose(0, 2, 1), "*": lambda a: a.conj()}[trans.lower()]
+    want = PR.dense_reference_solution(T.Problem(pr.rowPtrA, pr.colIndA, op(pr.A), pr.rowPtrX, pr.colIndX,
+                                                 pr.rowPtrB, pr.colIndB, pr.B, None, 1e-10))
+    st, X, info = T.solve_problem(pr, "z", threshold=1e-10, max_iterations=500, transA=trans)
+    assert st == 0 and np.abs(X - want).max() < 1e-8 * np.abs(want).max()
+
+
+def _user_array(blocks, layout, trans):
+    """what a caller would hand to setMatrix for complex blocks [n, R, C]"""
+    m = {"n": blocks, "t": blocks.transpose(0, 2, 1), "*": blocks.conj(), "c": blocks.conj().transpose(0, 2, 1)}[trans]
+    if layout == T.LAYOUT_RIRIRIRI:
+        return np.stack([m.real, m.imag], axis=-1).reshape(len(m), -1)
+    if layout == T.LAYOUT_RRRRIIII:
+        return np.stack([m.real, m.imag], axis=1).reshape(len(m), -1)
+    return np.stack([m.real, m.imag], axis=2).reshape(len(m), -1)  # RRIIRRII
+
+
+@pytest.mark.parametrize("prec", ["z", "c"])
+@pytest.mark.parametrize("shape", [(4, 4), (8, 10), (16, 32)])
+def test_set_get_matrix_layouts(prec, shape):
+    LM, LN = shape
+    pr = PR.stencil_2d(4, 3, LM, LN, 3, seed=12, radius=1.6)
+    rng = np.random.default_rng(3)
+    Xv = rng.standard_normal((pr.nnzbX, LM, LN)) + 1j * rng.standard_normal((pr.nnzbX, LM, LN))
+    real = np.float64 if prec == "z" else np.float32
+    with T.Solver() as s:
+        s.create_plan(pr)
+        s.set_buffer(nbytes=s.buffer_size(LM, LN, prec))
+        for lay_in in (T.LAYOUT_RIRIRIRI, T.LAYOUT_RRRRIIII, T.LAYOUT_RRIIRRII):
+            for tr_in in "nt*c":
+                s.set_matrix("X", _user_array(Xv, lay_in, tr_in).astype(real), tr_in, lay_in)
+                for lay_out in (T.LAYOUT_RIRIRIRI, T.LAYOUT_RRRRIIII, T.LAYOUT_RRIIRRII):
+                    for tr_out in "nt*c":
+                        got = s.get_matrix(trans=tr_out, layout=lay_out, raw=True)
+                        want = _user_array(Xv, lay_out, tr_out).astype(real)
+                        assert np.array_equal(got, want), (lay_in, tr_in, lay_out, tr_out)
+
+
+def _rand_pairs(rng, nY, nA, nX, maxp):
+    starts, pairs = [0], []
+    for _ in range(nY):
+        k = int(rng.integers(0, maxp + 1))
+        for _ in range(k):
+            pairs += [int(rng.integers(0, nA)), int(rng.integers(0, nX))]
+        starts.append(len(pairs) // 2)
+    return np.array(starts, np.uint32), np.array(pairs + [0, 0], np.uint32)[: max(2, len(pairs))]
+
+
+@pytest.mark.parametrize("prec", ["z", "c"])
+@pytest.mark.parametrize("size", SIZES)
+def test_multiply_all_block_sizes(torch_cuda, oracle, prec, size):
+    torch = torch_cuda
+    LM, LN = size
+    rng = np.random.default_rng(LM * 100 + LN)
+    nY, nA, nX = 37, 23, 29
+    starts, pairs = _rand_pairs(rng, nY, nA, nX, 6)
+    real = np.float64 if prec == "z" else np.float32
+    A = rng.uniform(-1, 1, (nA, 2, LM, LM)).astype(real)
+    X = rng.uniform(-1, 1, (nX, 2, LM, LN)).astype(real)
+    want = oracle.spmm(prec, LM, LN, starts, pairs, A, X.copy())[:nY] if nY <= nX else None
+    Yw = np.zeros((nY, 2, LM, LN), real)
+    Yw[:] = oracle.spmm(prec, LM, LN, starts, pairs, A, np.concatenate([X, np.zeros((max(0, nY - nX), 2, LM, LN), real)]))[:nY]
+    dA, dX = torch.from_numpy(A).cuda(), torch.from_numpy(X).cuda()
+    dS, dP = torch.from_numpy(starts.view(np.int32)).cuda(), torch.from_numpy(pairs.view(np.int32)).cuda()
+    dY = torch.full((nY, 2, LM, LN), 7.0, dtype=dA.dtype, device="cuda")
+    with T.Solver() as s:
+        st = T.lib.tfqmrgpuExt_multiply(s.handle, prec.encode(), LM, LN, nY, dS.data_ptr(), dP.data_ptr(),
+                                        dA.data_ptr(), dX.data_ptr(), dY.data_ptr())
+        assert st == 0
+        torch.cuda.synchronize()
+    got = dY.cpu().numpy()
+    eps = 1e-13 if prec == "z" else 2e-5
+    assert np.abs(got - Yw).max() <= eps * LM * 6, (size, prec)
+    del want
+
+
+def _load_plan_file():
+    # test/multiplication/plan_unordered.14-287-16 of the reference: "#nnzb_for_Y_A_X= nY nA nX", then iY iA iX beta
+    with gzip.open(os.path.join(GOLDEN, "plan_unordered.14-287-16.gz"), "rt") as f:
+        head = f.readline().split()
+        rows = np.loadtxt(f, dtype=np.int64)
+    nY, nA, nX = int(head[1]), int(head[2]), int(head[3])
+    starts, prev = [], -1
+    for n, (iy, ia, ix, beta) in enumerate(rows):  # groups by change of iY (bench_tfqmrgpu.cu:480-495)
+        if iy != prev:
+            assert beta == 0
+            starts.append(n)
+            prev = iy
+        else:
+            assert beta == 1
+    starts.append(len(rows))
+    return nY, nA, nX, np.array(starts, np.uint32), np.ascontiguousarray(rows[:, 1:3].reshape(-1).astype(np.uint32))
+
+
+@pytest.mark.parametrize("prec", ["z", "c"])
+def test_multiply_reference_plan_file(torch_cuda, oracle, prec):
+    # BASELINE config 1: the reference's multiplication benchmark input, cos/sin fill (bench_tfqmrgpu.cu:274-287),
+    # its acceptance test is maxdev <= 1e-4 (bench_tfqmrgpu.cu:414)
+    torch = torch_cuda
+    nY, nA, nX, starts, pairs = _load_plan_file()
+    assert (nY, nA, nX, len(pairs) // 2) == (4490, 13109, 4490, 50526)
+    LM = LN = 16
+    real = np.float64 if prec == "z" else np.float32
+
+    def fill(n):
+        arg = np.arange(n * LM * LN, dtype=np.float64).reshape(n, LM, LN)
+        return np.stack([np.cos(arg), np.sin(arg)], axis=1).astype(real)
+    A, X = fill(nA), fill(nX)
+    want = oracle.spmm(prec, LM, LN, starts, pairs, A, X)
+    dA, dX = torch.from_numpy(A).cuda(), torch.from_numpy(X).cuda()
+    dS, dP = torch.from_numpy(starts.view(np.int32)).cuda(), torch.from_numpy(pairs.view(np.int32)).cuda()
+    dY = torch.zeros_like(dX)
+    with T.Solver() as s:
+        assert T.lib.tfqmrgpuExt_multiply(s.handle, prec.encode(), LM, LN, nY, dS.data_ptr(), dP.data_ptr(),
+                                          dA.data_ptr(), dX.data_ptr(), dY.data_ptr()) == 0
+        torch.cuda.synchronize()
+    dev = np.abs(dY.cpu().numpy() - want).max()
+    assert dev <= (1e-12 if prec == "z" else 1e-4), dev
+
+
+@pytest.mark.parametrize("prec", ["z", "c"])
+@pytest.mark.parametrize("size", SIZES)
+def test_solve_all_block_sizes(oracle, prec, size):
+    LM, LN = size
+    pr = PR.stencil_2d(4, 4, LM, LN, 2, seed=LM + LN, radius=2.3)
+    tol = 1e-9 if prec == "z" else 1e-4
+    st, X, info = T.solve_problem(pr, prec, threshold=tol, max_iterations=100, shadow_mode=T.SHADOW_GLIBC_RAND)
+    st0, X0, info0 = oracle.solve(pr, prec, threshold=tol, max_iterations=100)
+    assert st == st0 == 0, (st, st0)
+    assert abs(info["iterations"] - info0["iterations"]) <= (0 if prec == "z" else 1)
+    assert np.abs(X - X0).max() <= _tol(prec) * np.abs(X0).max()
+
+
+def test_plan_reuse_and_status_codes():
+    pr = load_problem("fd_16x16_small")
+    with T.Solver() as s:
+        s.create_plan(pr)
+        s.set_buffer(nbytes=s.buffer_size(16, 16, "z"))
+        s.set_matrix("A", pr.A)
+        s.set_matrix("B", pr.B)
+        assert s.solve(1e-9, 2000) == 0
+        first, X1 = s.get_info(), s.get_matrix()
+        assert s.solve(1e-9, 2000) == 0                      # a second solve on the same plan (README.md:97-104)
+        again, X2 = s.get_info(), s.get_matrix()
+        assert first["iterations"] == again["iterations"] and np.array_equal(X1, X2)
+        assert again["flops_all"] == 2 * again["flops"]
+        s.set_matrix("B", 2 * pr.B)                          # new right-hand sides, same A
+        assert s.solve(1e-9, 2000) == 0
+        assert np.abs(s.get_matrix() - 2 * X1).max() <= 1e-7 * np.abs(X1).max()
+        assert s.solve(1e-9, 3) == 9                         # TFQMRGPU_STATUS_MAX_ITERATIONS, bare (tfqmrgpu_core.hxx:170)
+        assert s.get_info()["iterations"] == 3
+        assert s.solve(1e-9, 0) == 9
+        # precision mismatch: code 16 with the offending character (tfqmrgpu.cu:538-542)
+        a = np.zeros((pr.nnzbA, 16, 16, 2), np.float32)
+        st = T.lib.tfqmrgpu_bsrsv_setMatrix(s.handle, s.plan, b"A", T._ptr(a), b"c", 16, 16, b"n", 0x55)
+        assert T.decode(st)[::2] == (16, ord("c"))
+        s.set_matrix("A", 0 * pr.A)                          # A == 0: v3.(A v6) == 0 for every RHS -> breakdown
+        assert s.solve(1e-9, 50) == 6                        # TFQMRGPU_STATUS_BREAKDOWN (tfqmrgpu_core.hxx:258)
+
+
+def test_reduce_paths_single_rank(torch_cuda):
+    # the multi-GPU stopping test with one rank: host callback and RCCL must not change anything
+    pr = load_problem("fd_16x16_small")
+    st0, X0, info0 = T.solve_problem(pr, "z")
+    calls = []
+
+    def cb(ctx, values, n):
+        calls.append([values[i] for i in range(n)])
+    with T.Solver() as s:
+        s.create_plan(pr)
+        s.set_buffer(nbytes=s.buffer_size(16, 16, "z"))
+        s.set_matrix("A", pr.A)
+        s.set_matrix("B", pr.B)
+        keep = T.REDUCE_CB(cb)
+        assert T.lib.tfqmrgpuExt_setReduceCallback(s.handle, keep, None) == 0
+        assert s.solve(pr.tolerance, 2000) == 0
+        assert s.get_info()["iterations"] == info0["iterations"] and np.array_equal(s.get_matrix(), X0)
+        assert len(calls) >= 2 * info0["iterations"]
+        assert T.lib.tfqmrgpuExt_setReduceCallback(s.handle, C.cast(None, T.REDUCE_CB), None) == 0
+        uid = (C.c_char * 128)()
+        assert T.lib.tfqmrgpuExt_commUniqueId(uid) == 0
+        assert T.lib.tfqmrgpuExt_commInit(s.handle, 1, 0, uid) == 0
+        assert s.solve(pr.tolerance, 2000) == 0
+        assert s.get_info()["iterations"] == info0["iterations"] and np.array_equal(s.get_matrix(), X0)
+        assert T.lib.tfqmrgpuExt_commDestroy(s.handle) == 0
+
+
+def test_large_problem_properties(torch_cuda, oracle):
+    # size-independent checks at a size the oracle cannot solve in seconds: the solution must satisfy
+    # A*X == B on the pattern (checked with the device multiply, itself checked above), and the
+    # multiply must be linear
+    torch = torch_cuda
+    pr = PR.stencil_2d(48, 48, 16, 16, 24, seed=8, radius=9.0)
+    st, X, info = T.solve_problem(pr, "z", threshold=1e-9, max_iterations=300)
+    assert st == 0 and info["residual"] <= 1e-9
+    an = oracle.analyse(pr)
+    An = torch.from_numpy(oracle.a_native(pr.A, np.float64)).cuda()
+    Xn = torch.from_numpy(oracle.to_native(X, np.float64)).cuda()
+    dS = torch.from_numpy(an["starts"].view(np.int32)).cuda()
+    dP = torch.from_numpy(an["pairs"].view(np.int32)).cuda()
+    Y = torch.zeros_like(Xn)
+    with T.Solver() as s:
+        def mult(x, y):
+            assert T.lib.tfqmrgpuExt_multiply(s.handle, b"z", 16, 16, pr.nnzbX, dS.data_ptr(), dP.data_ptr(),
+                                              An.data_ptr(), x.data_ptr(), y.data_ptr()) == 0
+            torch.cuda.synchronize()
+        mult(Xn, Y)
+        R = oracle.from_native(Y.cpu().numpy())
+        R[an["subset"]] -= pr.B
+        col = an["colindx"].astype(np.int64)
+        res2 = np.zeros((an["nCols"], pr.LN))
+        np.add.at(res2, col, (np.abs(R) ** 2).sum(axis=1))
+        b2 = np.zeros((an["nCols"], pr.LN))
+        np.add.at(b2, col[an["subset"]], (np.abs(pr.B) ** 2).sum(axis=1))
+        assert np.sqrt((res2 / b2).max()) <= 1e-9
+        assert np.sqrt((res2 / b2).max()) == pytest.approx(info["residual"], rel=1e-6)
+        Z = torch.randn_like(Xn)
+        Y2, Y3 = torch.zeros_like(Xn), torch.zeros_like(Xn)
+        mult(Z, Y2)
+        mult(2.5 * Xn + Z, Y3)
+        assert (Y3 - (2.5 * Y + Y2)).abs().max().item() <= 1e-11 * Y3.abs().max().item()

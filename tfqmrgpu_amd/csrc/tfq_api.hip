@@ -1,0 +1,632 @@
+// C-ABI of libtfQMRgpu.so (include/tfqmrgpu.h, include/tfqmrgpu_ext.h) for MI355X.
+// Mirrors the entry points of real-space/tfQMRgpu tfQMRgpu/source/tfqmrgpu.cu (same names,
+// argument meaning and status codes); the implementation behind them is this library's own.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <algorithm>
+#include <new>
+#include <dlfcn.h>
+
+#include "tfq_device.hpp"
+#include "tfq_vec.hpp"
+
+using namespace tfq;
+
+namespace tfq {
+
+static inline char lower(char c) { return char(c | 32); }
+
+DevPlan resolve(Plan const& p) {
+    DevPlan d{};
+    char* b = p.buffer;
+    auto at = [&](Window const& w) { return (void*)(b + w.offset); };
+    d.LM = p.LM; d.LN = p.LN; d.dbl = ('z' == p.precision);
+    d.nCols = p.nCols; d.nnzbX = p.nnzbX; d.nnzbB = p.nnzbB; d.nnzbA = p.nnzbA;
+    d.nChunks = uint32_t(p.chunks.col.size());
+    d.x = at(p.wX); d.v4 = at(p.wV4); d.v5 = at(p.wV5); d.v6 = at(p.wV6); d.v7 = at(p.wV7);
+    d.v8 = at(p.wV8); d.v9 = at(p.wV9); d.B = at(p.wB); d.A = at(p.wA); d.v3 = (float*)at(p.wV3);
+    d.rho = at(p.wRho); d.alfa = at(p.wAlfa); d.beta = at(p.wBeta); d.c67 = at(p.wC67); d.eta = at(p.wEta);
+    d.z = (double*)at(p.wZ); d.d = (double*)at(p.wD); d.tau = (double*)at(p.wTau); d.var = (double*)at(p.wVar);
+    d.invBn2 = (double*)at(p.wInvBn2); d.status = (int8_t*)at(p.wStatus); d.ctl = (Ctl*)at(p.wCtl);
+    d.pz = (double*)at(p.wPz); d.pd = (double*)at(p.wPd); d.colrec = (double*)at(p.wColRec);
+    d.chunkFirst = (uint32_t*)at(p.wChunkFirst); d.chunkCol = (uint32_t*)at(p.wChunkCol);
+    d.colChunkPtr = (uint32_t*)at(p.wColChunkPtr); d.colStart = (uint32_t*)at(p.wColStart);
+    d.bOfX = (uint32_t*)at(p.wBofX); d.starts = (uint32_t*)at(p.wStarts); d.pairs = (uint32_t*)at(p.wPairs);
+    d.subset = (uint32_t*)at(p.wSubset); d.bColPtr = (uint32_t*)at(p.wBColPtr); d.bList = (uint32_t*)at(p.wBList);
+    d.u2i = (uint32_t*)at(p.wU2I); d.rowI = (uint32_t*)at(p.wRowI); d.origCol = (int32_t*)at(p.wOrigCol);
+    return d;
+}
+
+// glibc rand() (TYPE_3 additive feedback generator, seed 1) restated so that the shadow vector of
+// the reference CPU path (tfqmrgpu_linalg.hxx:799-802) can be reproduced in any process state
+struct GlibcRand {
+    uint32_t ring[31];
+    int f = 3, b = 0;      // r[i] = r[i-3] + r[i-31]
+    explicit GlibcRand(uint32_t seed = 1) {
+        int32_t word = int32_t(seed);
+        ring[0] = uint32_t(word);
+        for (int i = 1; i < 31; ++i) {          // srandom_r: Park-Miller steps fill the state
+            int32_t const hi = word / 127773, lo = word % 127773;
+            word = 16807 * lo - 2836 * hi;
+            if (word < 0) word += 2147483647;
+            ring[i] = uint32_t(word);
+        }
+        for (int i = 0; i < 310; ++i) (void)next();   // srandom_r discards 10*31 outputs
+    }
+    int32_t next() {
+        ring[f] += ring[b];
+        uint32_t const out = ring[f] >> 1;
+        f = (f + 1) % 31; b = (b + 1) % 31;
+        return int32_t(out);
+    }
+};
+
+static tfqmrgpuStatus_t hipCheck(hipError_t e, int code, int line) {
+    return (hipSuccess == e) ? TFQMRGPU_STATUS_SUCCESS : err(code, line % 10000);
+}
+#define TFQ_HIP(call, code) { auto const st_ = hipCheck((call), (code), __LINE__); if (st_) return st_; }
+
+// staging area for raw user blocks: the work vectors v4..v9 (free outside of solve)
+struct Stage { char* ptr; size_t bytes; };
+static Stage stage_of(Plan const& p) {
+    return { p.buffer + p.wV4.offset, (p.wV9.offset + p.wV9.bytes) - p.wV4.offset };
+}
+
+// move blocks between a host array in the caller's layout and a native device array
+static tfqmrgpuStatus_t transfer_blocks(Plan& p, hipStream_t s, int direction, bool dbl, void* native,
+    void* host, uint32_t const* u2n, uint32_t nBlocks, int nR, int nC, int layout, bool trans, bool conj)
+{
+    Stage const st = stage_of(p);
+    size_t const blockBytes = size_t(2) * nR * nC * (dbl ? 8 : 4);
+    size_t const cap = st.bytes / blockBytes;
+    if (cap < 1) return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED);
+    for (uint32_t first = 0; first < nBlocks; ) {
+        uint32_t const n = uint32_t(std::min<size_t>(cap, nBlocks - first));
+        char* h = (char*)host + size_t(first) * blockBytes;
+        if (0 == direction) {
+            TFQ_HIP(hipMemcpyAsync(st.ptr, h, n * blockBytes, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+            launch_convert(0, dbl, native, st.ptr, u2n, first, n, nR, nC, layout, trans, conj, s);
+        } else {
+            launch_convert(1, dbl, native, st.ptr, u2n, first, n, nR, nC, layout, trans, conj, s);
+            TFQ_HIP(hipMemcpyAsync(h, st.ptr, n * blockBytes, hipMemcpyDeviceToHost, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        }
+        // the stage is reused by the next batch and the host array belongs to the caller
+        TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        first += n;
+    }
+    TFQ_HIP(hipGetLastError(), TFQMRGPU_STATUS_LAUNCH_FAILED)
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+// ---- RCCL, loaded on first use so that single-GPU callers carry no dependency -------------------
+struct UidByValue { char internal[128]; };   // ncclUniqueId
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, UidByValue, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(void const*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    bool load();
+};
+static Rccl g_rccl;
+bool Rccl::load() {
+    if (lib) return true;
+    for (char const* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) return false;
+    GetUniqueId  = (decltype(GetUniqueId)) dlsym(lib, "ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+    CommDestroy  = (decltype(CommDestroy)) dlsym(lib, "ncclCommDestroy");
+    AllReduce    = (decltype(AllReduce))   dlsym(lib, "ncclAllReduce");
+    return GetUniqueId && CommInitRank && CommDestroy && AllReduce;
+}
+enum { kNcclDouble = 8, kNcclMax = 2 };
+
+// max-reduce ctl->red[off..off+1] over all ranks
+static tfqmrgpuStatus_t reduce_over_ranks(Handle& h, DevPlan const& d, int off, hipStream_t s) {
+    double* red = &d.ctl->red[off];
+    if (h.comm) {
+        int const rc = g_rccl.AllReduce(red, red, 2, kNcclDouble, kNcclMax, h.comm, s);
+        return rc ? TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED) : TFQMRGPU_STATUS_SUCCESS;
+    }
+    if (h.reduceFn) {
+        double v[2];
+        TFQ_HIP(hipMemcpyAsync(v, red, sizeof v, hipMemcpyDeviceToHost, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        h.reduceFn(h.reduceCtx, v, 2);
+        TFQ_HIP(hipMemcpyAsync(red, v, sizeof v, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+    }
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+// ---- the tfQMR driver -----------------------------------------------------------------------------
+// Algorithm = reference tfqmrgpu::solve (tfqmrgpu_core.hxx:179-306), restructured:
+//   dec35 | v6 | SpMM+v4+dot | dec34 | v7,v5,nrm | decT | x,v6,v7 | SpMM+v5+nrm+dot | decT | x | decide
+//   [ | SpMM residual | column records | decide ]   <- only does work when the bound asks for a probe
+// The host never waits for the iteration it has just enqueued: it keeps DEPTH iterations in flight
+// and reads the control block of iteration `it` (copied to pinned memory behind it) before it
+// enqueues iteration it+DEPTH.  Iterations enqueued after the solve has stopped cost a few empty
+// launches.  Every rank enqueues the same number of iterations, so collectives always match.
+static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
+    if (!p.buffer) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    if ('z' != p.precision && 'c' != p.precision) return err(TFQMRGPU_PRECISION_MISSMATCH, __LINE__ % 10000, p.precision);
+    hipStream_t const s = (hipStream_t)h.stream;
+    DevPlan const d = resolve(p);
+    bool const multi = (h.comm != nullptr) || (h.reduceFn != nullptr);
+
+    constexpr int DEPTH = 4;
+    Ctl* ring = nullptr;
+    TFQ_HIP(hipHostMalloc((void**)&ring, DEPTH * sizeof(Ctl), hipHostMallocDefault), TFQMRGPU_STATUS_ALLOCATION_FAILED)
+    hipEvent_t ev[DEPTH];
+    for (auto& e : ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+
+    p.boundHistory.clear();
+    p.iterations_needed = maxIt; p.flops_performed = 0;
+    vec_launch(VEC_SETUP, d, tol, maxIt, s);
+
+    tfqmrgpuStatus_t fail = TFQMRGPU_STATUS_SUCCESS;
+    auto enqueue = [&](int slot) {
+        vec_launch(VEC_DEC35, d, 0, 0, s);
+        vec_launch(VEC_XPAY_V6, d, 0, 0, s);
+        spmm_launch(EPI_XPAY_DOT, d, s);
+        vec_launch(VEC_DEC34, d, 0, 0, s);
+        vec_launch(VEC_V7_V5, d, 0, 0, s);
+        vec_launch(VEC_DECT_C67, d, 0, 0, s);
+        vec_launch(VEC_X_V6_V7, d, 0, 0, s);
+        spmm_launch(EPI_AXPY_NRM_DOT, d, s);
+        vec_launch(VEC_DECT_FIN, d, 0, 0, s);
+        vec_launch(VEC_X, d, 0, 0, s);
+        if (multi) {
+            launch_decide(d, 1, s);
+            auto const st = reduce_over_ranks(h, d, 0, s); if (st) fail = st;
+            launch_decide(d, 2, s);
+        } else launch_decide(d, 0, s);
+        spmm_launch(EPI_RESIDUAL, d, s);
+        vec_launch(VEC_PROBE_COL, d, 0, 0, s);
+        if (multi) {
+            launch_probe_decide(d, 1, s);
+            auto const st = reduce_over_ranks(h, d, 2, s); if (st) fail = st;
+            launch_probe_decide(d, 2, s);
+        } else launch_probe_decide(d, 0, s);
+        (void)hipMemcpyAsync(&ring[slot], d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s);
+        (void)hipEventRecord(ev[slot], s);
+    };
+
+    Ctl last{};
+    last.state = (maxIt > 0) ? 0 : 3; last.residual2_reached = 1e300; last.iterations_needed = maxIt;
+    int enq = 0, seen = 0;
+    while (enq < std::min(DEPTH, maxIt)) { enqueue(enq % DEPTH); ++enq; }
+    while (seen < enq && !fail) {
+        if (hipSuccess != hipEventSynchronize(ev[seen % DEPTH])) { fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED); break; }
+        last = ring[seen % DEPTH];
+        ++seen;
+        p.boundHistory.push_back(last.max_bound2);
+        if (last.state != 0) break;
+        if (enq < maxIt) { enqueue(enq % DEPTH); ++enq; }
+    }
+    (void)hipStreamSynchronize(s);
+    if (hipSuccess != hipGetLastError() && !fail) fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    (void)hipHostFree(ring);
+    if (fail) return fail;
+
+    // flop model of the reference: tfqmrgpu_linalg.hxx:587,625,684,703 and tfqmrgpu_blocksparse.hxx:198
+    double const blk = double(p.LM) * p.LN, nX = p.nnzbX;
+    double const fMult = double(p.nPairs()) * 8. * p.LM * blk, fDot = nX * 8. * blk, fNrm = nX * 4. * blk, fAxp = nX * 8. * blk;
+    p.flops_performed = fNrm + last.iteration * (2 * fMult + 2 * fDot + 2 * fNrm + 10 * fAxp) + last.nprobes * (fMult + fNrm);
+    p.flops_performed_all += p.flops_performed;
+    p.residuum_reached = std::sqrt(last.residual2_reached);
+    p.iterations_needed = (1 == last.state) ? last.iterations_needed : maxIt;
+    switch (last.state) {
+        case 1: return TFQMRGPU_STATUS_SUCCESS;
+        case 2: return TFQMRGPU_STATUS_BREAKDOWN;
+        default: return TFQMRGPU_STATUS_MAX_ITERATIONS;
+    }
+}
+
+static tfqmrgpuStatus_t upload(void* dst, void const* src, size_t bytes, hipStream_t s) {
+    if (0 == bytes) return TFQMRGPU_STATUS_SUCCESS;
+    TFQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+} // namespace tfq
+
+// ====================================================================================================
+extern "C" {
+
+tfqmrgpuStatus_t tfqmrgpu_bsrsv_allowedBlockSizes(int32_t* number, int32_t* blockSizes, int const arrayLength) {
+    // reference tfqmrgpu.cu:75-93, including its quirks: the output array is only cleared when
+    // *number != 0 on entry, and a pair is stored only while 2*n < arrayLength
+    if (nullptr == number) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    if (nullptr == blockSizes) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    if (0 != *number) for (int i = 0; i < arrayLength; ++i) blockSizes[i] = 0;
+    int n = 0, i = 0;
+    for (auto const& sz : kAllowedBlockSizes) {
+        ++n;
+        if (2 * n < arrayLength) { blockSizes[2 * i] = sz[0]; blockSizes[2 * i + 1] = sz[1]; ++i; }
+    }
+    *number = n;
+    return (n == i) ? TFQMRGPU_STATUS_SUCCESS : TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+}
+
+tfqmrgpuStatus_t tfqmrgpu_bsrsv_blockSizeMissing(int const ldA, int const ldB) {
+    // reference tfqmrgpu.cu:95-106: 12 + char=ldA + line=ldB
+    return blockSizeAllowed(ldA, ldB) ? 0 : err(TFQMRGPU_BLOCKSIZE_MISSING, ldB, ldA);
+}
+
+tfqmrgpuStatus_t tfqmrgpuCreateHandle(tfqmrgpuHandle_t* handle) {       // reference tfqmrgpu.cu:110-115
+    if (nullptr == handle)  return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    if (nullptr != *handle) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    auto h = new (std::nothrow) Handle();
+    if (!h) return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED);
+    *handle = (tfqmrgpuHandle_t)h;
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+tfqmrgpuStatus_t tfqmrgpuDestroyHandle(tfqmrgpuHandle_t handle) {       // reference tfqmrgpu.cu:117-121
+    if (nullptr == handle) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    auto h = (Handle*)handle;
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    delete h;
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+tfqmrgpuStatus_t tfqmrgpuSetStream(tfqmrgpuHandle_t handle, tfqmrgpuStream_t const streamId) { // tfqmrgpu.cu:124-128
+    if (nullptr == handle) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    ((Handle*)handle)->stream = (void*)streamId;
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+tfqmrgpuStatus_t tfqmrgpuGetStream(tfqmrgpuHandle_t handle, tfqmrgpuStream_t* streamId) {     // tfqmrgpu.cu:130-134
+    if (nullptr == handle || nullptr == streamId) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    *streamId = (tfqmrgpuStream_t)((Handle*)handle)->stream;
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+tfqmrgpuStatus_t tfqmrgpuCreateWorkspace(void** pBuffer, size_t const bytes, char const memType) { // tfqmrgpu.cu:682-694
+    if (nullptr == pBuffer) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    hipError_t const e = ('m' == lower(memType)) ? hipMallocManaged(pBuffer, bytes) : hipMalloc(pBuffer, bytes);
+    return (hipSuccess == e) ? TFQMRGPU_STATUS_SUCCESS : TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED);
+}
+
+tfqmrgpuStatus_t tfqmrgpuDestroyWorkspace(void* pBuffer) {              // tfqmrgpu.cu:696-698 (raw runtime code)
+    return (tfqmrgpuStatus_t)hipFree(pBuffer);
+}
+
+tfqmrgpuStatus_t tfqmrgpu_bsrsv_createPlan(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t* plan, int const mb,
+    int32_t const* bsrRowPtrA, int const nnzbA, int32_t const* bsrColIndA,
+    int32_t const* bsrRowPtrX, int const nnzbX, int32_t const* bsrColIndX,
+    int32_t const* bsrRowPtrB, int const nnzbB, int32_t const* bsrColIndB,
+    int const indexOffset, int const echo)
+{
+    (void)handle;
+    if (nullptr == plan)  return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    if (nullptr != *plan) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);     // tfqmrgpu.cu:161
+    auto p = new (std::nothrow) Plan();
+    if (!p) return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED);
+    p->indexOffset = indexOffset;
+    auto const st = analyse(*p, mb, bsrRowPtrA, nnzbA, bsrColIndA, bsrRowPtrX, nnzbX, bsrColIndX,
+                            bsrRowPtrB, nnzbB, bsrColIndB, indexOffset, echo);
+    if (st) { delete p; return st; }   // (the reference leaks the plan on its error paths)
+    *plan = (tfqmrgpuBsrsvPlan_t)p;
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+tfqmrgpuStatus_t tfqmrgpu_bsrsv_destroyPlan(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan) { // tfqmrgpu.cu:353-361
+    (void)handle;
+    auto p = asPlan(plan);
+    if (!p) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    p->magic = 0;
+    delete p;
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+tfqmrgpuStatus_t tfqmrgpu_bsrsv_bufferSize(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan,
+    int const ldA, int const blockDim, int const ldB, int const RhsBlockDim, char const precision, size_t* pBufferSizeInBytes)
+{
+    // reference tfqmrgpu.cu:364-412
+    int const LM = ldA, LN = ldB;
+    if (LM != blockDim)    return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    if (LM > LN)           return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    if (LN != RhsBlockDim) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    auto p = asPlan(plan);
+    if (!p || !handle) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    char prec;
+    switch (lower(precision)) {            // f,c -> c ; m -> m ; everything else -> z  (tfqmrgpu.cu:383-390)
+        case 'f': case 'c': prec = 'c'; break;
+        case 'm': prec = 'm'; break;
+        default:  prec = 'z';
+    }
+    if (nullptr == pBufferSizeInBytes) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    if (!blockSizeAllowed(LM, LN)) return err(TFQMRGPU_BLOCKSIZE_MISSING, LN, LM); // tfqmrgpu.cu:70
+    // 'm' is accepted here and refused by solve, as in the reference (tfqmrgpu.cu:42-44); size it like 'c'
+    auto const st = layoutBuffer(*p, LM, LN, ('m' == prec) ? 'c' : prec);
+    p->precision = prec;
+    p->buffer = nullptr;
+    *pBufferSizeInBytes = p->bufferBytes;
+    return st;
+}
+
+tfqmrgpuStatus_t tfqmrgpu_bsrsv_setBuffer(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, void* const pBuffer) {
+    // reference tfqmrgpu.cu:415-450: register the buffer, create v3, upload the index lists
+    if (nullptr == pBuffer) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    auto p = asPlan(plan); auto h = (Handle*)handle;
+    if (!p || !h) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    if (0 == p->LM) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);        // bufferSize has not been called
+    hipStream_t const s = (hipStream_t)h->stream;
+    p->buffer = (char*)pBuffer;
+    auto at = [&](Window const& w) { return (void*)(p->buffer + w.offset); };
+    auto up = [&](Window const& w, void const* src, size_t bytes) { return upload(at(w), src, bytes, s); };
+    tfqmrgpuStatus_t st;
+    auto const& c = p->chunks;
+    std::vector<int32_t> orig(p->original_bsrColIndX);
+    for (auto& o : orig) o -= p->indexOffset;
+    if ((st = up(p->wChunkFirst, c.first.data(), c.first.size() * 4))) return st;
+    if ((st = up(p->wChunkCol, c.col.data(), c.col.size() * 4))) return st;
+    if ((st = up(p->wColChunkPtr, c.colPtr.data(), c.colPtr.size() * 4))) return st;
+    if ((st = up(p->wColStart, p->colStart.data(), p->colStart.size() * 4))) return st;
+    if ((st = up(p->wOrigCol, orig.data(), orig.size() * 4))) return st;
+    if ((st = up(p->wBofX, p->bOfX.data(), p->bOfX.size() * 4))) return st;
+    if ((st = up(p->wStarts, p->starts_i.data(), p->starts_i.size() * 4))) return st;
+    if ((st = up(p->wPairs, p->pairs_i.data(), p->pairs_i.size() * 4))) return st;
+    if ((st = up(p->wSubset, p->subset_i.data(), p->subset_i.size() * 4))) return st;
+    if ((st = up(p->wBColPtr, p->bColPtr.data(), p->bColPtr.size() * 4))) return st;
+    if ((st = up(p->wBList, p->bList.data(), p->bList.size() * 4))) return st;
+    if ((st = up(p->wU2I, p->u2i.data(), p->u2i.size() * 4))) return st;
+    if ((st = up(p->wRowI, p->rowI.data(), p->rowI.size() * 4))) return st;
+    TFQ_HIP(hipMemsetAsync(at(p->wCtl), 0, p->wCtl.bytes, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+    TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)     // host vectors above go out of scope
+    DevPlan const d = resolve(*p);
+    if (TFQMRGPU_SHADOW_GLIBC_RAND == p->shadowMode) {
+        size_t const n = size_t(p->nnzbX) * 2 * p->LM * p->LN;
+        std::vector<float> v3(n);
+        GlibcRand rng(1);
+        float const denom = 1. / 2147483647;                            // tfqmrgpu_linalg.hxx:799-801
+        for (size_t i = 0; i < n; ++i) v3[i] = rng.next() * denom;
+        st = transfer_blocks(*p, s, 0, false, d.v3, v3.data(), d.u2i, p->nnzbX, p->LM, p->LN, TFQMRGPU_LAYOUT_RRRRIIII, false, false);
+        if (st) return st;
+    } else {
+        launch_shadow_hash(d, s);
+        if (hipSuccess != hipGetLastError()) return TFQ_ERR(TFQMRGPU_STATUS_RANDOM_GEN_FAILED);
+    }
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+tfqmrgpuStatus_t tfqmrgpu_bsrsv_getBuffer(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, void** pBuffer) { // tfqmrgpu.cu:453-462
+    (void)handle;
+    auto p = asPlan(plan);
+    if (!p || !pBuffer) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    *pBuffer = (void*)p->buffer;
+    return (nullptr == *pBuffer) ? TFQ_ERR(TFQMRGPU_POINTER_INVALID) : TFQMRGPU_STATUS_SUCCESS;
+}
+
+// reference tfqmrgpu::set_or_getMatrix, tfqmrgpu.cu:467-603
+static tfqmrgpuStatus_t set_or_get(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, char const var, void* values,
+    char const precision, char const transposition, tfqmrgpuDataLayout_t const layout, bool const is_get)
+{
+    switch (layout) {
+        case TFQMRGPU_LAYOUT_RRRRIIII: case TFQMRGPU_LAYOUT_RIRIRIRI: case TFQMRGPU_LAYOUT_RRIIRRII: break;
+        default: return err(TFQMRGPU_DATALAYOUT_UNKNOWN, layout % 10000);          // line field = layout
+    }
+    bool conj = false, trans = false;
+    char const tr = lower(transposition);   // '*' | 32 == '*'
+    switch (tr) {
+        case 'h': case 'c': conj = true; trans = true; break;
+        case '*': conj = true; break;
+        case 't': trans = true; break;
+        case 'n': break;
+        default: return err(TFQMRGPU_TANSPOSITION_UNKNOWN, __LINE__ % 10000, tr);
+    }
+    auto p = asPlan(plan); auto h = (Handle*)handle;
+    if (!p || !h) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    if (0 == p->LM) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    uint32_t nnzb = 0; int nR = p->LM, nC = p->LN; int which = 0;
+    switch (lower(var)) {
+        case 'a': nnzb = p->nnzbA; nC = p->LM; trans = !trans; which = 0; break; // A is stored transposed (tfqmrgpu.cu:514-517)
+        case 'b': nnzb = p->nnzbB; which = 1; break;
+        case 'x': nnzb = p->nnzbX; which = 2; break;
+        default: return err(TFQMRGPU_VARIABLENAME_UNKNOWN, __LINE__ % 10000, var);
+    }
+    if (nnzb < 1) return TFQMRGPU_STATUS_SUCCESS;
+    if (nullptr == p->buffer) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    bool const is_double = ('z' == p->precision);
+    if (('z' == lower(precision)) != is_double) return err(TFQMRGPU_PRECISION_MISSMATCH, __LINE__ % 10000, precision);
+    if (nullptr == values) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    hipStream_t const s = (hipStream_t)h->stream;
+    DevPlan const d = resolve(*p);
+    void* native = (0 == which) ? d.A : (1 == which) ? d.B : d.x;
+    uint32_t const* u2n = (2 == which) ? d.u2i : nullptr;
+    auto const st = transfer_blocks(*p, s, is_get ? 1 : 0, is_double, native, values, u2n, nnzb, nR, nC, layout, trans, conj);
+    if (!st && 1 == which) p->haveB = true;
+    return st;
+}
+
+tfqmrgpuStatus_t tfqmrgpu_bsrsv_setMatrix(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, char const var,
+    void const* val, char const precision, int const ld, int const d2, char const trans, tfqmrgpuDataLayout_t const layout)
+{
+    (void)ld; (void)d2;   // ignored by the reference as well (tfqmrgpu.cu:615-616)
+    return set_or_get(handle, plan, var, (void*)val, precision, trans, layout, false);
+}
+
+tfqmrgpuStatus_t tfqmrgpu_bsrsv_getMatrix(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, char const var,
+    void* val, char const precision, int const ld, int const d2, char const trans, tfqmrgpuDataLayout_t const layout)
+{
+    (void)ld; (void)d2;
+    if ('x' != lower(var)) return err(TFQMRGPU_UNDOCUMENTED_ERROR, __LINE__ % 10000, var);  // only X (tfqmrgpu.cu:635-643)
+    return set_or_get(handle, plan, var, val, precision, trans, layout, true);
+}
+
+tfqmrgpuStatus_t tfqmrgpu_bsrsv_solve(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, double const threshold, int const maxIterations) {
+    auto p = asPlan(plan); auto h = (Handle*)handle;                    // tfqmrgpu.cu:648-661
+    if (!p || !h) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    return run_solve(*h, *p, threshold, maxIterations);
+}
+
+tfqmrgpuStatus_t tfqmrgpu_bsrsv_getInfo(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan,
+    double* residuum_reached, int32_t* iterations_needed, double* flops_performed, double* flops_performed_all)
+{
+    (void)handle;                                                        // tfqmrgpu.cu:663-679
+    auto p = asPlan(plan);
+    if (!p) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    int any = 0;
+    if (residuum_reached)    { ++any; *residuum_reached = p->residuum_reached; }
+    if (iterations_needed)   { ++any; *iterations_needed = p->iterations_needed; }
+    if (flops_performed)     { ++any; *flops_performed = p->flops_performed; }
+    if (flops_performed_all) { ++any; *flops_performed_all = p->flops_performed_all; }
+    return any ? TFQMRGPU_STATUS_SUCCESS : TFQMRGPU_STATUS_NO_INFO_PASSED;
+}
+
+} // extern "C"
+
+// one-call drivers, reference tfqmrgpu.cu:702-821
+template <typename real_t>
+static tfqmrgpuStatus_t bsrsv_onecall(int mb, int ldA, int ldB,
+    int32_t const* rowPtrA, int nnzbA, int32_t const* colIndA, real_t const* Amat, char transA,
+    int32_t const* rowPtrX, int nnzbX, int32_t const* colIndX, real_t* Xmat, char transX,
+    int32_t const* rowPtrB, int nnzbB, int32_t const* colIndB, real_t const* Bmat, char transB,
+    int32_t* iterations, float* residual, int indexOffset, int echo)
+{
+    char const zoc = (sizeof(real_t) == 8) ? 'z' : 'c';
+    char const* const me = (zoc == 'z') ? "tfqmrgpu_bsrsv_z" : "tfqmrgpu_bsrsv_c";
+    tfqmrgpuStatus_t stat;
+    tfqmrgpuHandle_t handle = nullptr;
+    tfqmrgpuBsrsvPlan_t plan = nullptr;
+    void* buffer = nullptr;
+    size_t bytes = 0;
+    auto cleanup = [&]() {      // (the reference returns early and leaks on errors)
+        if (buffer) tfqmrgpuDestroyWorkspace(buffer);
+        if (plan) tfqmrgpu_bsrsv_destroyPlan(handle, plan);
+        if (handle) tfqmrgpuDestroyHandle(handle);
+    };
+#define TFQ_STEP(call, name) stat = (call); if (stat) { if (echo > 0) std::printf("# %s: %s returned %d\n", me, name, stat); cleanup(); return stat; }
+    if (echo > 0) std::printf("# %s: mb= %d, ldA= %d, ldB= %d, iterations= %d, residual= %.1e\n", me, mb, ldA, ldB,
+                              iterations ? *iterations : 200, residual ? *residual : 1e-9);
+    TFQ_STEP(tfqmrgpuCreateHandle(&handle), "tfqmrgpuCreateHandle")
+    TFQ_STEP(tfqmrgpuSetStream(handle, 0), "tfqmrgpuSetStream")
+    TFQ_STEP(tfqmrgpu_bsrsv_createPlan(handle, &plan, mb, rowPtrA, nnzbA, colIndA, rowPtrX, nnzbX, colIndX,
+                                       rowPtrB, nnzbB, colIndB, indexOffset, echo), "tfqmrgpu_bsrsv_createPlan")
+    TFQ_STEP(tfqmrgpu_bsrsv_bufferSize(handle, plan, ldA, ldA, ldB, ldB, zoc, &bytes), "tfqmrgpu_bsrsv_bufferSize")
+    TFQ_STEP(tfqmrgpuCreateWorkspace(&buffer, bytes, 'd'), "tfqmrgpuCreateWorkspace")
+    TFQ_STEP(tfqmrgpu_bsrsv_setBuffer(handle, plan, buffer), "tfqmrgpu_bsrsv_setBuffer")
+    TFQ_STEP(tfqmrgpu_bsrsv_setMatrix(handle, plan, 'A', Amat, zoc, ldA, ldA, transA, TFQMRGPU_LAYOUT_RIRIRIRI), "tfqmrgpu_bsrsv_setMatrix('A')")
+    TFQ_STEP(tfqmrgpu_bsrsv_setMatrix(handle, plan, 'B', Bmat, zoc, ldB, ldA, transB, TFQMRGPU_LAYOUT_RIRIRIRI), "tfqmrgpu_bsrsv_setMatrix('B')")
+    double const threshold = residual ? *residual : 1e-9;
+    int const maxiter = iterations ? *iterations : 200;
+    TFQ_STEP(tfqmrgpu_bsrsv_solve(handle, plan, threshold, maxiter), "tfqmrgpu_bsrsv_solve")
+    double residuum = 0, flops = 0, flops_all = 0; int32_t needed = 0;
+    TFQ_STEP(tfqmrgpu_bsrsv_getInfo(handle, plan, &residuum, &needed, &flops, &flops_all), "tfqmrgpu_bsrsv_getInfo")
+    if (echo > 1) std::printf("# tfQMRgpu needed %d iterations to converge to %.1e using %g GFlop\n", needed, residuum, flops * 1e-9);
+    if (residual) *residual = float(residuum);
+    if (iterations) *iterations = needed;
+    TFQ_STEP(tfqmrgpu_bsrsv_getMatrix(handle, plan, 'X', Xmat, zoc, ldB, ldA, transX, TFQMRGPU_LAYOUT_RIRIRIRI), "tfqmrgpu_bsrsv_getMatrix")
+#undef TFQ_STEP
+    cleanup();
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+extern "C" {
+
+tfqmrgpuStatus_t tfqmrgpu_bsrsv_z(int mb, int ldA, int ldB,
+    int32_t const* rowPtrA, int nnzbA, int32_t const* colIndA, double const* Amat, char transA,
+    int32_t const* rowPtrX, int nnzbX, int32_t const* colIndX, double* Xmat, char transX,
+    int32_t const* rowPtrB, int nnzbB, int32_t const* colIndB, double const* Bmat, char transB,
+    int32_t* iterations, float* residual, int indexOffset, int echo)
+{
+    return bsrsv_onecall<double>(mb, ldA, ldB, rowPtrA, nnzbA, colIndA, Amat, transA, rowPtrX, nnzbX, colIndX, Xmat, transX,
+                                 rowPtrB, nnzbB, colIndB, Bmat, transB, iterations, residual, indexOffset, echo);
+}
+
+tfqmrgpuStatus_t tfqmrgpu_bsrsv_c(int mb, int ldA, int ldB,
+    int32_t const* rowPtrA, int nnzbA, int32_t const* colIndA, float const* Amat, char transA,
+    int32_t const* rowPtrX, int nnzbX, int32_t const* colIndX, float* Xmat, char transX,
+    int32_t const* rowPtrB, int nnzbB, int32_t const* colIndB, float const* Bmat, char transB,
+    int32_t* iterations, float* residual, int indexOffset, int echo)
+{
+    return bsrsv_onecall<float>(mb, ldA, ldB, rowPtrA, nnzbA, colIndA, Amat, transA, rowPtrX, nnzbX, colIndX, Xmat, transX,
+                                rowPtrB, nnzbB, colIndB, Bmat, transB, iterations, residual, indexOffset, echo);
+}
+
+// ---- extensions (include/tfqmrgpu_ext.h) --------------------------------------------------------------
+
+tfqmrgpuStatus_t tfqmrgpuExt_planView(tfqmrgpuBsrsvPlan_t plan, tfqmrgpuPlanView_t* v) {
+    auto p = asPlan(plan);
+    if (!p || !v) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    v->nRows = p->nRows; v->nCols = p->nCols; v->nnzbA = p->nnzbA; v->nnzbX = p->nnzbX; v->nnzbB = p->nnzbB;
+    v->nPairs = p->nPairs();
+    v->pairs = p->pairs.data(); v->starts = p->starts.data(); v->subset = p->subset.data();
+    v->colindx = p->colindx.data(); v->original_bsrColIndX = p->original_bsrColIndX.data();
+    v->LM = p->LM; v->LN = p->LN; v->precision = p->precision;
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+int32_t tfqmrgpuExt_getBoundHistory(tfqmrgpuBsrsvPlan_t plan, double* bound2, int32_t capacity) {
+    auto p = asPlan(plan);
+    if (!p) return -1;
+    auto const n = int32_t(p->boundHistory.size());
+    for (int32_t i = 0; i < std::min(n, capacity); ++i) if (bound2) bound2[i] = p->boundHistory[i];
+    return n;
+}
+
+tfqmrgpuStatus_t tfqmrgpuExt_setShadowMode(tfqmrgpuBsrsvPlan_t plan, int mode) {
+    auto p = asPlan(plan);
+    if (!p) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    if (mode != TFQMRGPU_SHADOW_HASH && mode != TFQMRGPU_SHADOW_GLIBC_RAND) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    p->shadowMode = mode;
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+tfqmrgpuStatus_t tfqmrgpuExt_setShadowVector(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, float const* v3) {
+    auto p = asPlan(plan); auto h = (Handle*)handle;
+    if (!p || !h || !v3 || !p->buffer) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    DevPlan const d = resolve(*p);
+    return transfer_blocks(*p, (hipStream_t)h->stream, 0, false, d.v3, (void*)v3, d.u2i, p->nnzbX, p->LM, p->LN,
+                           TFQMRGPU_LAYOUT_RRRRIIII, false, false);
+}
+
+tfqmrgpuStatus_t tfqmrgpuExt_multiply(tfqmrgpuHandle_t handle, char precision, int lm, int ln,
+    uint32_t nnzbY, uint32_t const* starts_d, uint32_t const* pairs_d, void const* A_d, void const* X_d, void* Y_d)
+{
+    auto h = (Handle*)handle;
+    if (!h || !starts_d || !pairs_d || !A_d || !X_d || !Y_d) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    return launch_multiply(precision, lm, ln, nnzbY, starts_d, pairs_d, A_d, X_d, Y_d, (hipStream_t)h->stream);
+}
+
+tfqmrgpuStatus_t tfqmrgpuExt_commUniqueId(char id[128]) {
+    if (!id) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    if (!g_rccl.load()) return TFQ_ERR(TFQMRGPU_NO_IMPLEMENTATION);
+    return g_rccl.GetUniqueId(id) ? TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED) : TFQMRGPU_STATUS_SUCCESS;
+}
+
+tfqmrgpuStatus_t tfqmrgpuExt_commInit(tfqmrgpuHandle_t handle, int nranks, int rank, char const id[128]) {
+    auto h = (Handle*)handle;
+    if (!h || !id) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    if (!g_rccl.load()) return TFQ_ERR(TFQMRGPU_NO_IMPLEMENTATION);
+    UidByValue u; std::memcpy(u.internal, id, 128);
+    void* comm = nullptr;
+    if (g_rccl.CommInitRank(&comm, nranks, u, rank)) return TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
+    h->comm = comm; h->nranks = nranks; h->rank = rank;
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+tfqmrgpuStatus_t tfqmrgpuExt_commDestroy(tfqmrgpuHandle_t handle) {
+    auto h = (Handle*)handle;
+    if (!h) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    h->comm = nullptr; h->nranks = 1; h->rank = 0;
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+tfqmrgpuStatus_t tfqmrgpuExt_setReduceCallback(tfqmrgpuHandle_t handle, tfqmrgpuReduceMax_t fn, void* ctx) {
+    auto h = (Handle*)handle;
+    if (!h) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    h->reduceFn = fn; h->reduceCtx = ctx;
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+} // extern "C"

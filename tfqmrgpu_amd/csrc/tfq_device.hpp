@@ -1,0 +1,68 @@
+// Structures shared between the host driver and the HIP kernels.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <hip/hip_runtime.h>
+
+#include "tfq_plan.hpp"
+
+namespace tfq {
+
+// Device-resident control block of one solve.  The stopping logic of the reference runs on the
+// host after two blocking copies per iteration (tfqmrgpu_core.hxx:235-304); here it runs in tiny
+// kernels that update this record, every other kernel looks at `state`/`probe` first and
+// returns when it has nothing to do.  The host only reads a copy of it, a few iterations late.
+struct Ctl {
+    double tol2;               // threshold^2
+    double target_bound2;      // probe when bound2 <= target_bound2
+    double max_bound2;         // bound2 of the latest iteration: max_rhs(tau/|b|^2) * (2 it + 1)
+    double residual2_reached;  // max_rhs |A x - b|^2/|b|^2 at the latest probe
+    double red[4];             // {max tau/|b|^2, any RHS alive, max res^2, any RHS unconverged}
+    int32_t iteration;         // completed iterations
+    int32_t maxIterations;
+    int32_t state;             // 0 running, 1 converged, 2 all RHS broke down, 3 out of iterations
+    int32_t probe;             // the true residual has to be computed now
+    int32_t iterations_needed;
+    int32_t nprobes;
+    int32_t pad[2];
+};
+static_assert(sizeof(Ctl) == 96, "Ctl is copied as 96 bytes");
+
+// device pointers of one plan (all inside the user's work buffer)
+struct DevPlan {
+    int LM, LN;
+    bool dbl;
+    uint32_t nCols, nnzbX, nnzbB, nnzbA, nChunks;
+    void *x, *v4, *v5, *v6, *v7, *v8, *v9, *B, *A;
+    float* v3;
+    void *rho, *alfa, *beta, *c67, *eta;       // [nCols][2][LN] real
+    double *z, *d, *tau, *var, *invBn2;        // [nCols][2|1][LN]
+    int8_t* status;                            // [nCols][LN]
+    Ctl* ctl;
+    double *pz, *pd;                           // [nChunks][2|1][LN]
+    double* colrec;                            // [nCols][2]
+    uint32_t const *chunkFirst, *chunkCol, *colChunkPtr, *colStart, *bOfX;
+    uint32_t const *starts, *pairs, *subset, *bColPtr, *bList, *u2i, *rowI;
+    int32_t const* origCol;
+};
+
+DevPlan resolve(Plan const& p);
+
+enum { EPI_NONE = 0, EPI_XPAY_DOT = 1, EPI_AXPY_NRM_DOT = 2, EPI_RESIDUAL = 3 };
+
+// ---- launchers (tfq_kernels*.hip); all asynchronous on `s` ---------------------------------------
+void launch_decide(DevPlan const& d, int phase, hipStream_t s); // phase 0: all, 1: reduce columns only, 2: update ctl only
+void launch_probe_decide(DevPlan const& d, int phase, hipStream_t s);
+
+// y[iY] = sum A*X over the pair list, device pointers, native layout (tfqmrgpu_ext.h section 3)
+tfqmrgpuStatus_t launch_multiply(char precision, int lm, int ln, uint32_t nnzbY,
+    uint32_t const* starts, uint32_t const* pairs, void const* A, void const* X, void* Y, hipStream_t s);
+
+// layout conversion between the caller's block layout and the native one (tfq_layout.hip)
+// direction 0: user -> native (setMatrix), 1: native -> user (getMatrix); one batch of user blocks
+// [firstUser, firstUser + nBlocks) whose raw bytes sit in `stage`; u2n: user -> native block index
+void launch_convert(int direction, bool dbl, void* native, void* stage, uint32_t const* u2n,
+    uint32_t firstUser, uint32_t nBlocks, int nR, int nC, int layout, bool trans, bool conj, hipStream_t s);
+void launch_shadow_hash(DevPlan const& d, hipStream_t s);
+
+} // namespace tfq

@@ -1,0 +1,284 @@
+// Index analysis of A*X==B (host only) and the device buffer layout.
+//
+// analyse() restates what the reference does in tfqmrgpu_bsrsv_createPlan
+// (real-space/tfQMRgpu tfQMRgpu/source/tfqmrgpu.cu:161-339): the results `pairs`, `starts`,
+// `subset`, `colindx`, `original_bsrColIndX`, `nCols` are bit-identical, including the order
+// of the pair list (block row, then X-block order inside the row, then A-block order inside
+// the row) and the "first match wins" rule of its linear search (bsr.hxx:27-39).
+// The search itself is done with one sorted (column, position) list per block row, so the
+// cost is O(nPairs log) instead of the reference's O(nnzbX * nnz/rowA * nnz/rowX).
+#include "tfq_plan.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cmath>
+#include <numeric>
+
+namespace tfq {
+
+int const kAllowedBlockSizes[15][2] = {
+    { 4, 4}, { 4, 5}, { 4, 8}, { 4,32}, { 8, 8}, { 8, 9}, { 8,10}, { 8,32}, { 8,64},
+    {16,16}, {16,32}, {16,64}, {32,32}, {32,64}, {64,64}};
+
+bool blockSizeAllowed(int lm, int ln) {
+    for (auto const& s : kAllowedBlockSizes) if (s[0] == lm && s[1] == ln) return true;
+    return false;
+}
+
+namespace {
+
+// per block row: (raw column index, position) sorted, to find the FIRST block with a given column
+struct RowLookup {
+    std::vector<std::pair<int32_t, int32_t>> key; // sorted by (col, pos)
+    std::vector<int64_t> rowBegin;                // [mb+1]
+    void build(int mb, int32_t const* rowPtr, int32_t const* colInd, int off) {
+        rowBegin.resize(mb + 1);
+        int64_t n = 0;
+        for (int r = 0; r < mb; ++r) { rowBegin[r] = n; n += std::max(0, rowPtr[r + 1] - rowPtr[r]); }
+        rowBegin[mb] = n;
+        key.resize(n);
+        for (int r = 0; r < mb; ++r) {
+            auto w = rowBegin[r];
+            for (int32_t q = rowPtr[r] - off; q < rowPtr[r + 1] - off; ++q) key[w++] = {colInd[q], q};
+            std::sort(key.begin() + rowBegin[r], key.begin() + rowBegin[r + 1]);
+        }
+    }
+    // first position in row r whose raw column equals `col`, or -1
+    int32_t find(int r, int32_t col) const {
+        auto b = key.begin() + rowBegin[r], e = key.begin() + rowBegin[r + 1];
+        auto it = std::lower_bound(b, e, std::make_pair(col, int32_t(-2147483647 - 1)));
+        return (it != e && it->first == col) ? it->second : -1;
+    }
+};
+
+} // namespace
+
+tfqmrgpuStatus_t analyse(Plan& p, int mb,
+    int32_t const* rowPtrA, int nnzbA, int32_t const* colIndA,
+    int32_t const* rowPtrX, int nnzbX, int32_t const* colIndX,
+    int32_t const* rowPtrB, int nnzbB, int32_t const* colIndB,
+    int indexOffset, int echo)
+{
+    // plausibility checks, same order as the reference (tfqmrgpu.cu:166-172)
+    if (mb < 1)        return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    if (nnzbX < 1)     return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    if (nnzbB > nnzbX) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    if (int64_t(nnzbA) > int64_t(mb) * mb) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    if (!rowPtrA || !rowPtrX || !rowPtrB) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    if (nnzbA != rowPtrA[mb] - rowPtrA[0]) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    if (nnzbX != rowPtrX[mb] - rowPtrX[0]) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    if (nnzbB != rowPtrB[mb] - rowPtrB[0]) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    if ((nnzbA > 0 && !colIndA) || !colIndX || (nnzbB > 0 && !colIndB)) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+
+    int const off = indexOffset;
+    // the reference trusts its inputs beyond this point; a library that launches device kernels
+    // from these lists must not, so malformed row pointers / columns of A are rejected here
+    for (int r = 0; r < mb; ++r) {
+        if (rowPtrA[r + 1] < rowPtrA[r] || rowPtrX[r + 1] < rowPtrX[r] || rowPtrB[r + 1] < rowPtrB[r])
+            return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    }
+    if (rowPtrA[0] != off || rowPtrX[0] != off || rowPtrB[0] != off) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    for (int q = 0; q < nnzbA; ++q) {
+        auto const k = colIndA[q] - off;
+        if (k < 0 || k >= mb) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    }
+
+    p.nRows = mb; p.nnzbA = nnzbA; p.nnzbX = nnzbX; p.nnzbB = nnzbB;
+
+    RowLookup look;
+    look.build(mb, rowPtrX, colIndX, off);
+
+    // ---- pair list of Y = A*X, Y has the pattern of X (tfqmrgpu.cu:183-230) ----------------
+    p.starts.assign(size_t(nnzbX) + 1, 0);
+    p.pairs.clear();
+    p.pairs.reserve(2 * (size_t(nnzbX) * size_t(nnzbA) / size_t(mb) + 1));
+    p.rowOfX.resize(nnzbX);
+    for (int irow = 0; irow < mb; ++irow) {
+        for (int32_t inzy = rowPtrX[irow] - off; inzy < rowPtrX[irow + 1] - off; ++inzy) {
+            p.rowOfX[inzy] = irow;
+            auto const jcol = colIndX[inzy]; // raw (offset included), compared with raw values
+            for (int32_t inza = rowPtrA[irow] - off; inza < rowPtrA[irow + 1] - off; ++inza) {
+                auto const krow = colIndA[inza] - off;
+                auto const inzx = look.find(krow, jcol);
+                if (inzx >= 0) { p.pairs.push_back(uint32_t(inza)); p.pairs.push_back(uint32_t(inzx)); }
+            }
+            p.starts[size_t(inzy) + 1] = uint32_t(p.pairs.size() / 2);
+        }
+    }
+    p.pairs.shrink_to_fit();
+    if (echo > 6) std::printf("# tfqmrgpu_bsrsv_createPlan: found %zu pairs in A*X multiplication\n", p.nPairs());
+
+    // ---- B must live on blocks of X (tfqmrgpu.cu:233-251) ---------------------------------------
+    p.subset.assign(nnzbB, 0);
+    for (int irow = 0; irow < mb; ++irow) {
+        for (int32_t inzb = rowPtrB[irow] - off; inzb < rowPtrB[irow + 1] - off; ++inzb) {
+            auto const inzx = look.find(irow, colIndB[inzb]);
+            if (inzx < 0) {
+                if (echo > 0) std::printf("# tfqmrgpu_bsrsv_createPlan: in row #%d B has col #%d but X does not!\n",
+                                          irow + off, colIndB[inzb]);
+                return err(TFQMRGPU_B_IS_NOT_SUBSET_OF_X, irow); // the row travels in the line field
+            }
+            p.subset[inzb] = uint32_t(inzx);
+        }
+    }
+
+    // ---- compress the block columns of X (tfqmrgpu.cu:254-315) ------------------------------
+    int32_t lo = 2147483647, hi = -2147483647;
+    for (int q = 0; q < nnzbX; ++q) { lo = std::min(lo, colIndX[q]); hi = std::max(hi, colIndX[q]); }
+    int64_t const nc = int64_t(hi) - lo + 1;
+    if (nc < 1) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    if (echo > 5) std::printf("# tfqmrgpu_bsrsv_createPlan: column indices of X are in [%d, %d]\n", lo, hi);
+    std::vector<uint32_t> perCol(nc, 0);
+    for (int q = 0; q < nnzbX; ++q) ++perCol[colIndX[q] - lo];
+    std::vector<int32_t> jc2jb(nc, -1);
+    uint32_t nb = 0, nempty = 0;
+    for (int64_t jc = 0; jc < nc; ++jc) { if (perCol[jc]) jc2jb[jc] = int32_t(nb++); else ++nempty; }
+    if (echo > 5) std::printf("# tfqmrgpu_bsrsv_createPlan: found %u empty columns and %u columns with entries\n", nempty, nb);
+    if (nempty > 0 && echo > 0) std::printf("# tfqmrgpu_bsrsv_createPlan: found %u empty columns in X!\n", nempty);
+    if (nb < 1) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    p.nCols = nb;
+    p.colindx.resize(nnzbX);
+    p.col32.resize(nnzbX);
+    p.original_bsrColIndX.assign(nb, 0);
+    for (int q = 0; q < nnzbX; ++q) {
+        auto const jb = uint32_t(jc2jb[colIndX[q] - lo]);
+        p.original_bsrColIndX[jb] = colIndX[q];
+        p.colindx[q] = uint16_t(jb);   // the reference's colIndex_t is 16 bit (tfqmrgpu.hxx:59)
+        p.col32[q] = jb;
+    }
+
+    // ---- every column of X needs a block of B (tfqmrgpu.cu:316-337) ---------------------------
+    {
+        std::vector<uint32_t> bPerCol(nb, 0);
+        for (int q = 0; q < nnzbB; ++q) ++bPerCol[p.col32[p.subset[q]]];
+        uint32_t nzero = 0;
+        for (uint32_t jb = 0; jb < nb; ++jb) nzero += (bPerCol[jb] < 1);
+        if (nzero > 0) {
+            if (echo > 0) std::printf("# tfqmrgpu_bsrsv_createPlan: found %u zero columns in B!\n", nzero);
+            return err(TFQMRGPU_B_HAS_A_ZERO_COLUMN, int(nzero)); // the count travels in the line field
+        }
+    }
+
+    // ==== MI355X device order: X-shaped vectors sorted by (compressed column, block row) =========
+    // Every vector kernel then works on runs of blocks that share one column (uniform per-RHS
+    // scalars, register-level reductions), and a shard of columns is one contiguous range.
+    p.i2u.resize(nnzbX);
+    std::iota(p.i2u.begin(), p.i2u.end(), 0u);
+    std::stable_sort(p.i2u.begin(), p.i2u.end(), [&](uint32_t a, uint32_t b) {
+        if (p.col32[a] != p.col32[b]) return p.col32[a] < p.col32[b];
+        return p.rowOfX[a] < p.rowOfX[b];
+    });
+    p.u2i.resize(nnzbX);
+    for (uint32_t i = 0; i < uint32_t(nnzbX); ++i) p.u2i[p.i2u[i]] = i;
+    p.colStart.assign(size_t(nb) + 1, 0);
+    for (int q = 0; q < nnzbX; ++q) ++p.colStart[p.col32[q] + 1];
+    for (uint32_t jb = 0; jb < nb; ++jb) p.colStart[jb + 1] += p.colStart[jb];
+
+    p.starts_i.assign(size_t(nnzbX) + 1, 0);
+    p.pairs_i.resize(p.pairs.size());
+    {
+        size_t w = 0;
+        for (uint32_t i = 0; i < uint32_t(nnzbX); ++i) {
+            auto const u = p.i2u[i];
+            for (auto q = p.starts[u]; q < p.starts[u + 1]; ++q) {
+                p.pairs_i[2 * w]     = p.pairs[2 * size_t(q)];
+                p.pairs_i[2 * w + 1] = p.u2i[p.pairs[2 * size_t(q) + 1]];
+                ++w;
+            }
+            p.starts_i[i + 1] = uint32_t(w);
+        }
+    }
+    p.subset_i.resize(nnzbB);
+    p.bcol.resize(nnzbB);
+    {
+        std::vector<uint8_t> seen(nnzbX, 0);
+        for (int q = 0; q < nnzbB; ++q) {
+            p.subset_i[q] = p.u2i[p.subset[q]];
+            p.bcol[q] = p.col32[p.subset[q]];
+            // two blocks of B on the same block of X would make the scatter ambiguous on a GPU
+            if (seen[p.subset[q]]) return TFQ_ERR(TFQMRGPU_NO_IMPLEMENTATION);
+            seen[p.subset[q]] = 1;
+        }
+    }
+    p.bOfX.assign(nnzbX, 0xffffffffu);
+    for (int q = 0; q < nnzbB; ++q) p.bOfX[p.subset_i[q]] = uint32_t(q);
+    p.bColPtr.assign(size_t(nb) + 1, 0);
+    for (int q = 0; q < nnzbB; ++q) ++p.bColPtr[p.bcol[q] + 1];
+    for (uint32_t jb = 0; jb < nb; ++jb) p.bColPtr[jb + 1] += p.bColPtr[jb];
+    p.bList.resize(nnzbB);
+    {
+        std::vector<uint32_t> fill(p.bColPtr.begin(), p.bColPtr.end() - 1);
+        for (int q = 0; q < nnzbB; ++q) p.bList[fill[p.bcol[q]]++] = uint32_t(q);
+    }
+    p.rowI.resize(nnzbX);
+    for (uint32_t i = 0; i < uint32_t(nnzbX); ++i) p.rowI[i] = p.rowOfX[p.i2u[i]];
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device buffer layout.  The reference carves its buffer in tfqmrgpu_core.hxx:49-84 and
+// tfqmrgpu_blocksparse.hxx:46-51 (X first, 256-byte granules, tfqmrgpu_util.hxx:56-82); the
+// layout here is this library's own: no 2^ceil(log2 nnzbX) reduction scratch (zvv/dvv), instead
+// one small partial-sum record per chunk.
+tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
+    p.LM = LM; p.LN = LN; p.precision = precision;
+    p.realBytes = ('z' == precision) ? 8 : 4;
+    size_t const blockElems = size_t(2) * LM * LN;
+    p.S = size_t(p.nnzbX) * blockElems * p.realBytes;
+
+    // chunks: runs of blocks inside one column, sized so that a chunk of one vector is 8..64 KiB
+    // and the grid has a few thousand work groups when the problem is large enough
+    {
+        size_t const blockBytes = blockElems * p.realBytes;
+        size_t target = p.S / 4096;
+        target = std::min<size_t>(std::max<size_t>(target, 8 * 1024), 64 * 1024);
+        uint32_t const CH = uint32_t(std::max<size_t>(1, target / blockBytes));
+        auto& c = p.chunks;
+        c.first.clear(); c.col.clear(); c.colPtr.assign(size_t(p.nCols) + 1, 0);
+        for (uint32_t jb = 0; jb < p.nCols; ++jb) {
+            c.colPtr[jb] = uint32_t(c.col.size());
+            for (uint32_t b = p.colStart[jb]; b < p.colStart[jb + 1]; b += CH) { c.first.push_back(b); c.col.push_back(jb); }
+        }
+        c.colPtr[p.nCols] = uint32_t(c.col.size());
+        c.first.push_back(p.nnzbX);
+    }
+    size_t const nChunks = p.chunks.col.size();
+
+    size_t at = 0;
+    auto take = [&](Window& w, size_t bytes) { w.offset = at; w.bytes = bytes; at = align256(at + bytes); };
+    take(p.wX, p.S);                                  // the solution stays first, as in the reference
+    take(p.wV4, p.S); take(p.wV5, p.S); take(p.wV6, p.S);
+    take(p.wV7, p.S); take(p.wV8, p.S); take(p.wV9, p.S);
+    take(p.wV3, size_t(p.nnzbX) * blockElems * sizeof(float)); // the shadow vector is float for 'z' too
+    take(p.wB, size_t(p.nnzbB) * blockElems * p.realBytes);
+    size_t const cs = size_t(p.nCols) * 2 * LN * p.realBytes;
+    take(p.wRho, cs); take(p.wAlfa, cs); take(p.wBeta, cs); take(p.wC67, cs); take(p.wEta, cs);
+    take(p.wZ,   size_t(p.nCols) * 2 * LN * sizeof(double));
+    take(p.wD,   size_t(p.nCols) * LN * sizeof(double));
+    take(p.wTau, size_t(p.nCols) * LN * sizeof(double));
+    take(p.wVar, size_t(p.nCols) * LN * sizeof(double));
+    take(p.wInvBn2, size_t(p.nCols) * LN * sizeof(double));
+    take(p.wStatus, size_t(p.nCols) * LN);
+    take(p.wCtl, 4096);
+    take(p.wPz, nChunks * 2 * LN * sizeof(double));
+    take(p.wPd, nChunks * LN * sizeof(double));
+    take(p.wColRec, size_t(p.nCols) * 2 * sizeof(double)); // per-column stopping-test record
+    take(p.wChunkFirst, (nChunks + 1) * sizeof(uint32_t));
+    take(p.wChunkCol, nChunks * sizeof(uint32_t));
+    take(p.wColChunkPtr, (size_t(p.nCols) + 1) * sizeof(uint32_t));
+    take(p.wColStart, (size_t(p.nCols) + 1) * sizeof(uint32_t));
+    take(p.wOrigCol, size_t(p.nCols) * sizeof(int32_t));
+    take(p.wBofX, size_t(p.nnzbX) * sizeof(uint32_t));         // B block on each X block or ~0
+    take(p.wStarts, p.starts_i.size() * sizeof(uint32_t));
+    take(p.wPairs, p.pairs_i.size() * sizeof(uint32_t));
+    take(p.wSubset, size_t(p.nnzbB) * sizeof(uint32_t));
+    take(p.wBColPtr, (size_t(p.nCols) + 1) * sizeof(uint32_t));
+    take(p.wBList, size_t(p.nnzbB) * sizeof(uint32_t));
+    take(p.wU2I, size_t(p.nnzbX) * sizeof(uint32_t));
+    take(p.wRowI, size_t(p.nnzbX) * sizeof(uint32_t));
+    take(p.wA, size_t(p.nnzbA) * 2 * LM * LM * p.realBytes);
+    p.bufferBytes = at + 256;
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+} // namespace tfq

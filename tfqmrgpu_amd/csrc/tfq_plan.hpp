@@ -1,0 +1,115 @@
+// Host-side plan of one bsrsv problem: the reference-visible analysis results
+// (bit-exact with real-space/tfQMRgpu createPlan, tfqmrgpu.cu:136-351) plus the
+// MI355X-specific device layout derived from them.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <vector>
+
+#include "tfqmrgpu.h"
+#include "tfqmrgpu_ext.h"
+
+namespace tfq {
+
+// error code packing (tfqmrgpu.h:179-181 of the reference)
+inline tfqmrgpuStatus_t err(int code, int line = 0, int key = 0) {
+    return code + TFQMRGPU_CODE_LINE * line + TFQMRGPU_CODE_CHAR * key;
+}
+#define TFQ_ERR(code) ::tfq::err((code), __LINE__ % 10000)
+
+inline size_t align256(size_t n) { return (n + 255) & ~size_t(255); }
+
+struct Window { size_t offset = 0, bytes = 0; };
+
+// one unit of work of the vector kernels: a run of blocks inside ONE block column
+struct ChunkTable {
+    std::vector<uint32_t> first;   // [nChunks+1] first internal block of each chunk
+    std::vector<uint32_t> col;     // [nChunks]   compressed block column
+    std::vector<uint32_t> colPtr;  // [nCols+1]   first chunk of each column
+};
+
+struct Handle {
+    void* stream = nullptr;               // hipStream_t
+    // multi-GPU stopping test (tfqmrgpu_ext.h section 4)
+    void* comm = nullptr;                 // ncclComm_t, RCCL loaded lazily
+    int nranks = 1, rank = 0;
+    tfqmrgpuReduceMax_t reduceFn = nullptr;
+    void* reduceCtx = nullptr;
+};
+
+struct Plan {
+    uint32_t magic = 0x7f51a9d3u;
+
+    // ---- analysis results, identical to the reference's bsrsv_plan_t members ----------
+    uint32_t nRows = 0, nCols = 0, nnzbA = 0, nnzbX = 0, nnzbB = 0;
+    int indexOffset = 0;
+    std::vector<uint32_t> pairs;               // [2*nPairs] (inzA, inzX), user order
+    std::vector<uint32_t> starts;              // [nnzbX+1]
+    std::vector<uint32_t> subset;              // [nnzbB]
+    std::vector<uint16_t> colindx;             // [nnzbX]
+    std::vector<int32_t>  original_bsrColIndX; // [nCols]
+
+    // ---- internal (device) order of the X-shaped vectors: sorted by (column, row) --------
+    std::vector<uint32_t> col32;       // [nnzbX] compressed column of each user block (32 bit)
+    std::vector<uint32_t> rowOfX;      // [nnzbX] block row of each user block
+    std::vector<uint32_t> u2i, i2u;    // user index <-> internal index
+    std::vector<uint32_t> colStart;    // [nCols+1] internal block range of each column
+    std::vector<uint32_t> starts_i;    // [nnzbX+1] pair list regrouped by internal Y index
+    std::vector<uint32_t> pairs_i;     // [2*nPairs] (inzA user, inzX internal)
+    std::vector<uint32_t> subset_i;    // [nnzbB] internal X index of each B block
+    std::vector<uint32_t> bcol;        // [nnzbB] compressed column of each B block
+    std::vector<uint32_t> bColPtr, bList; // B blocks grouped by compressed column
+    std::vector<uint32_t> bOfX;        // [nnzbX] internal order: B block sitting on this X block, or ~0
+    std::vector<uint32_t> rowI;        // [nnzbX] block row, internal order
+    ChunkTable chunks;
+
+    // ---- fixed by bufferSize -----------------------------------------------------------------
+    int LM = 0, LN = 0;
+    char precision = 0;                // 'c' or 'z' (or 'm', accepted but not solvable)
+    size_t realBytes = 0;              // 4 or 8
+    size_t S = 0;                      // bytes of one X-shaped vector
+    size_t bufferBytes = 0;
+
+    // windows into the user's device buffer
+    Window wX, wV4, wV5, wV6, wV7, wV8, wV9, wV3, wB, wA;
+    Window wRho, wAlfa, wBeta, wC67, wEta;     // [nCols][2][LN] real
+    Window wZ, wD, wTau, wVar, wInvBn2;        // double scalars per right-hand side
+    Window wStatus;                            // int8 [nCols][LN]
+    Window wCtl;                               // device control block (see tfq_solver)
+    Window wPz, wPd;                           // per-chunk partial sums (double)
+    Window wColRec;                            // per-column stopping-test record [nCols][2] double
+    Window wChunkFirst, wChunkCol, wColChunkPtr, wColStart, wOrigCol, wBofX;
+    Window wStarts, wPairs, wSubset, wBColPtr, wBList, wU2I, wRowI;
+
+    char* buffer = nullptr;            // device buffer registered by setBuffer
+    int shadowMode = TFQMRGPU_SHADOW_HASH;
+    bool haveB = false;
+
+    // ---- results of the last solve -------------------------------------------------------------
+    double residuum_reached = 0, flops_performed = -1, flops_performed_all = 0;
+    int iterations_needed = -1;
+    std::vector<double> boundHistory;
+
+    size_t nPairs() const { return pairs.size() / 2; }
+};
+
+inline Plan* asPlan(tfqmrgpuBsrsvPlan_t p) {
+    auto q = reinterpret_cast<Plan*>(p);
+    return (q && q->magic == 0x7f51a9d3u) ? q : nullptr;
+}
+
+// index analysis, tfq_plan.cpp
+tfqmrgpuStatus_t analyse(Plan& p, int mb,
+    int32_t const* rowPtrA, int nnzbA, int32_t const* colIndA,
+    int32_t const* rowPtrX, int nnzbX, int32_t const* colIndX,
+    int32_t const* rowPtrB, int nnzbB, int32_t const* colIndB,
+    int indexOffset, int echo);
+
+// derive chunk tables + buffer windows for (LM, LN, precision); tfq_plan.cpp
+tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision);
+
+// the 15 compiled (ldA, ldB) pairs of the reference (allowed_block_sizes.h:4-18)
+extern int const kAllowedBlockSizes[15][2];
+bool blockSizeAllowed(int lm, int ln);
+
+} // namespace tfq

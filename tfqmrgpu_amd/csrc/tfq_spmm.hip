@@ -1,0 +1,341 @@
+// Block-sparse multiply Y = A*X for gfx950 (MI355X), with the vector updates that follow it in
+// the tfQMR iteration fused into the epilogue.
+//
+// Contract (same as the reference kernel gemmNxNf, real-space/tfQMRgpu tfqmrgpu_blockmult.hxx:9-93
+// and its launcher tfqmrgpu_blocksparse.hxx:71-199):
+//     Y[iY][c][i][j] = sum_{p in starts[iY]..starts[iY+1]} sum_k A[pairs[2p]][c'][k][i] * X[pairs[2p+1]][c''][k][j]
+// complex arithmetic on split Re/Im planes, A blocks stored transposed ([k][i]), accumulation in the
+// storage precision.  Flop count nPairs*8*LM*LM*LN (tfqmrgpu_blocksparse.hxx:198).
+//
+// Two implementations:
+//  * k_spmm_mfma : LM and LN multiples of 16.  One wavefront owns a 16 x LN strip of one Y block
+//    and keeps it in MFMA accumulators (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32).  The
+//    native layouts ARE the MFMA operand layouts: lane l feeds A[k0 + l/16][i0 + l%16] and
+//    X[k0 + l/16][j0 + l%16], i.e. four consecutive 128-byte rows per load instruction, so operands go
+//    global -> VGPR fully coalesced with no LDS transpose.  4 real MFMA chains per complex product
+//    (-Im(A) is formed once per operand).
+//  * k_spmm_direct : every other block shape (LM in {4, 8}, LN in {5, 9, 10, ...}); one thread per
+//    output element, operands through the vector L1.
+// A work group processes one chunk (run of Y blocks of one block column, tfq_plan.cpp), so the
+// per-RHS scalars of the epilogue are uniform and the dot / norm contributions leave the work group
+// as one [LN] record (deterministic order).
+#include "tfq_device.hpp"
+#include "tfq_vec.hpp"
+
+namespace tfq {
+
+struct SpmmArgs {
+    void* Y; void const* A; void const* X;
+    uint32_t const* starts; uint32_t const* pairs;
+    uint32_t nY;                       // number of Y blocks (plain mode)
+    uint32_t const* chunkFirst;        // nullptr: plain mode, chunk b = blocks [b*CH, (b+1)*CH)
+    uint32_t const* chunkCol;
+    uint32_t CH;
+    Ctl const* ctl; int gate;          // 0: always run, 1: skip when the solve has stopped, 2: only when probing
+    void* e0; void const* e1; void const* sc; float const* v3;
+    void const* B; uint32_t const* bOfX;
+    double* pz; double* pd;
+};
+
+template <int EPI> struct EpiPlanes { static constexpr int N = (EPI == EPI_XPAY_DOT) ? 2 : (EPI == EPI_AXPY_NRM_DOT) ? 3 : (EPI == EPI_RESIDUAL) ? 1 : 0; };
+
+// per-element epilogue; off = offset of the element's real part in an X-shaped vector, P = plane size
+template <typename R, int EPI>
+__device__ inline void epilogue(SpmmArgs const& a, size_t off, int P, R yr, R yi, R sr, R si,
+                                uint32_t bq, int eoff, double* acc /* [planes] */)
+{
+    if constexpr (EPI == EPI_NONE) {
+        ((R*)a.Y)[off] = yr; ((R*)a.Y)[off + P] = yi;
+    } else if constexpr (EPI == EPI_XPAY_DOT) {
+        // v9 := A v6 (kept for the v5 update); v4 := v8 + beta v4; v4 := v9 + beta v4; pz += v3 . v4
+        // (tfqmrgpu_core.hxx:196-202)
+        ((R*)a.Y)[off] = yr; ((R*)a.Y)[off + P] = yi;
+        R* v4 = (R*)a.e0; R const* v8 = (R const*)a.e1;
+        R ur = v4[off], ui = v4[off + P];
+        R const xr = v8[off], xi = v8[off + P];
+        R tr = xr + sr * ur - si * ui, ti = xi + si * ur + sr * ui;
+        ur = yr + sr * tr - si * ti; ui = yi + si * tr + sr * ti;
+        v4[off] = ur; v4[off + P] = ui;
+        double const wr = a.v3[off], wi = a.v3[off + P], dr = ur, di = ui;
+        acc[0] += dr * wr - di * wi;
+        acc[1] += dr * wi + di * wr;
+    } else if constexpr (EPI == EPI_AXPY_NRM_DOT) {
+        // v8 := A v6; v5 := alfa v8 + v5; pd += |v5|^2; pz += v3 . v5  (tfqmrgpu_core.hxx:224-228,189)
+        ((R*)a.Y)[off] = yr; ((R*)a.Y)[off + P] = yi;
+        R* v5 = (R*)a.e0;
+        R ur = v5[off], ui = v5[off + P];
+        R const nr = sr * yr - si * yi + ur, ni = si * yr + sr * yi + ui;
+        v5[off] = nr; v5[off + P] = ni;
+        double const wr = a.v3[off], wi = a.v3[off + P], dr = nr, di = ni;
+        acc[0] += dr * wr - di * wi;
+        acc[1] += dr * wi + di * wr;
+        acc[2] += dr * dr + di * di;
+    } else { // EPI_RESIDUAL: |A x - b|^2, nothing stored (tfqmrgpu_core.hxx:265-269)
+        R rr = yr, ri = yi;
+        if (bq != 0xffffffffu) {
+            R const* b = (R const*)a.B + size_t(bq) * 2 * P;
+            rr += R(-1) * b[eoff]; ri += R(-1) * b[eoff + P];
+        }
+        double const dr = rr, di = ri;
+        acc[0] += dr * dr + di * di;
+    }
+}
+
+template <int EPI>
+__device__ inline void write_record(SpmmArgs const& a, uint32_t chunk, int LN, int p, int j, double v) {
+    if constexpr (EPI == EPI_XPAY_DOT) a.pz[(size_t(chunk) * 2 + p) * LN + j] = v;
+    else if constexpr (EPI == EPI_AXPY_NRM_DOT) { if (p < 2) a.pz[(size_t(chunk) * 2 + p) * LN + j] = v; else a.pd[size_t(chunk) * LN + j] = v; }
+    else if constexpr (EPI == EPI_RESIDUAL) a.pd[size_t(chunk) * LN + j] = v;
+}
+
+__device__ inline bool gate_closed(SpmmArgs const& a) {
+    if (a.gate == 0) return false;
+    if (a.ctl->state != 0) return true;
+    return (a.gate == 2 && a.ctl->probe == 0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// one thread per output element
+template <typename R, int LM, int LN, int EPI>
+__global__ __launch_bounds__(256) void k_spmm_direct(SpmmArgs a) {
+    if (gate_closed(a)) return;
+    constexpr int P = LM * LN;                       // elements per plane
+    constexpr int NACC = (P >= 256) ? P / 256 : 1;   // outputs per thread
+    constexpr int GRP = (P >= 256) ? 1 : 256 / P;    // Y blocks in flight per work group
+    constexpr int NPL = EpiPlanes<EPI>::N;
+    static_assert(P < 256 || P % 256 == 0, "block does not tile the work group");
+    int const t = threadIdx.x;
+    int const g = (P >= 256) ? 0 : t / P;
+    int const e0 = (P >= 256) ? t : t % P;
+    bool const active = (g < GRP);
+    uint32_t const chunk = blockIdx.x;
+    uint32_t first, last, col = 0;
+    if (a.chunkFirst) { first = a.chunkFirst[chunk]; last = a.chunkFirst[chunk + 1]; col = a.chunkCol[chunk]; }
+    else { first = chunk * a.CH; last = min(first + a.CH, a.nY); }
+
+    int const j = e0 % LN;                           // 256 % LN == 0 whenever NACC > 1
+    R sr = 0, si = 0;
+    if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
+        sr = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + j];
+        si = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + j];
+    }
+    double part[NPL > 0 ? NPL : 1] = {};
+
+    if (active) for (uint32_t y = first + g; y < last; y += GRP) {
+        R yr[NACC], yi[NACC];
+#pragma unroll
+        for (int n = 0; n < NACC; ++n) { yr[n] = 0; yi[n] = 0; }
+        for (uint32_t q = a.starts[y]; q < a.starts[y + 1]; ++q) {
+            R const* Ab = (R const*)a.A + size_t(a.pairs[2 * size_t(q)]) * 2 * LM * LM;
+            R const* Xb = (R const*)a.X + size_t(a.pairs[2 * size_t(q) + 1]) * 2 * P;
+#pragma unroll
+            for (int n = 0; n < NACC; ++n) {
+                int const e = e0 + n * 256, i = e / LN;
+                R cr = 0, ci = 0;
+#pragma unroll 4
+                for (int k = 0; k < LM; ++k) {
+                    R const ar = Ab[k * LM + i], ai = Ab[LM * LM + k * LM + i];
+                    R const xr = Xb[k * LN + j], xi = Xb[P + k * LN + j];
+                    cr += ar * xr - ai * xi;
+                    ci += ar * xi + ai * xr;
+                }
+                yr[n] += cr; yi[n] += ci;
+            }
+        }
+        uint32_t bq = 0xffffffffu;
+        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
+#pragma unroll
+        for (int n = 0; n < NACC; ++n) {
+            int const e = e0 + n * 256;
+            epilogue<R, EPI>(a, size_t(y) * 2 * P + e, P, yr[n], yi[n], sr, si, bq, e, part);
+        }
+    }
+
+    if constexpr (NPL > 0) {
+        // threads that share j: rank = position among them; sum in rank order
+        constexpr int RANKS = (P >= 256) ? 256 / LN : GRP * LM;
+        __shared__ double s[NPL * LN * RANKS];
+        int const rank = (P >= 256) ? t / LN : g * LM + e0 / LN;
+        if (active)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) s[(p * LN + j) * RANKS + rank] = part[p];
+        __syncthreads();
+        for (int e = t; e < NPL * LN; e += 256) {
+            double sum = 0;
+            for (int r = 0; r < RANKS; ++r) sum += s[e * RANKS + r];
+            write_record<EPI>(a, chunk, LN, e / LN, e % LN, sum);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// MFMA kernel: LM % 16 == 0, LN % 16 == 0
+using d4 = __attribute__((ext_vector_type(4))) double;
+using f4 = __attribute__((ext_vector_type(4))) float;
+template <typename R> struct Acc;
+template <> struct Acc<double> {
+    using T = d4;
+    __device__ static inline T mma(double a, double b, T c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    // C/D layout of v_mfma_f64_16x16x4_f64: register r of lane l is row (l/16) + 4 r, column l%16
+    __device__ static inline int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <> struct Acc<float> {
+    using T = f4;
+    __device__ static inline T mma(float a, float b, T c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    // C/D layout of v_mfma_f32_16x16x4_f32: register r of lane l is row 4 (l/16) + r, column l%16
+    __device__ static inline int row(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+template <typename R, int LM, int LN, int EPI>
+__global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
+    if (gate_closed(a)) return;
+    static_assert(LM % 16 == 0 && LN % 16 == 0, "MFMA tiles are 16 x 16");
+    constexpr int P = LM * LN, MT = LM / 16, NT = LN / 16;
+    constexpr int NPL = EpiPlanes<EPI>::N;
+    using T4 = typename Acc<R>::T;
+    int const lane = threadIdx.x & 63;
+    int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int const lr = lane >> 4, lc = lane & 15;
+    uint32_t const chunk = blockIdx.x;
+    uint32_t first, last, col = 0;
+    if (a.chunkFirst) { first = a.chunkFirst[chunk]; last = a.chunkFirst[chunk + 1]; col = a.chunkCol[chunk]; }
+    else { first = chunk * a.CH; last = min(first + a.CH, a.nY); }
+
+    R sr[NT], si[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { sr[nt] = 0; si[nt] = 0; }
+    if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            sr[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + nt * 16 + lc];
+            si[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + nt * 16 + lc];
+        }
+    }
+    double part[NPL > 0 ? NPL : 1][NT] = {};
+
+    uint32_t const nUnits = (last - first) * MT;     // unit = 16-row strip of one Y block
+    for (uint32_t u = wave; u < nUnits; u += 4) {
+        uint32_t const y = first + u / MT;
+        int const i0 = int(u % MT) * 16;
+        T4 cre[NT], cim[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { cre[nt] = T4{0, 0, 0, 0}; cim[nt] = T4{0, 0, 0, 0}; }
+        uint32_t const q0 = a.starts[y], q1 = a.starts[y + 1];
+        for (uint32_t q = q0; q < q1; ++q) {
+            R const* Ab = (R const*)a.A + size_t(a.pairs[2 * size_t(q)]) * 2 * LM * LM + i0 + lc;
+            R const* Xb = (R const*)a.X + size_t(a.pairs[2 * size_t(q) + 1]) * 2 * P + lc;
+#pragma unroll 4
+            for (int k0 = 0; k0 < LM; k0 += 4) {
+                int const k = k0 + lr;
+                R const ar = Ab[k * LM], ai = Ab[LM * LM + k * LM];
+                R const nai = -ai;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    R const xr = Xb[k * LN + nt * 16], xi = Xb[P + k * LN + nt * 16];
+                    cre[nt] = Acc<R>::mma(ar, xr, cre[nt]);
+                    cim[nt] = Acc<R>::mma(ar, xi, cim[nt]);
+                    cre[nt] = Acc<R>::mma(nai, xi, cre[nt]);
+                    cim[nt] = Acc<R>::mma(ai, xr, cim[nt]);
+                }
+            }
+        }
+        uint32_t bq = 0xffffffffu;
+        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int const e = (i0 + Acc<R>::row(lane, r)) * LN + nt * 16 + lc;
+                double acc[NPL > 0 ? NPL : 1] = {};
+                epilogue<R, EPI>(a, size_t(y) * 2 * P + e, P, cre[nt][r], cim[nt][r], sr[nt], si[nt], bq, e, acc);
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) part[p][nt] += acc[p];
+            }
+        }
+    }
+
+    if constexpr (NPL > 0) {
+        // rows live on lane/16 (and registers): add the four lane groups, then the four waves in order
+        __shared__ double s[4][NPL][LN];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                double v = part[p][nt];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (lane < 16) s[wave][p][nt * 16 + lane] = v;
+            }
+        __syncthreads();
+        for (int e = threadIdx.x; e < NPL * LN; e += 256) {
+            int const p = e / LN, j = e % LN;
+            double const sum = ((s[0][p][j] + s[1][p][j]) + s[2][p][j]) + s[3][p][j];
+            write_record<EPI>(a, chunk, LN, p, j, sum);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename R, int LM, int LN, int EPI>
+static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
+    if (0 == nWG) return;
+    if constexpr (LM % 16 == 0 && LN % 16 == 0) k_spmm_mfma<R, LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
+    else k_spmm_direct<R, LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
+}
+
+template <typename R, int LM, int LN>
+static void spmm_epi(int epi, SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
+    switch (epi) {
+    case EPI_NONE:         spmm_go<R, LM, LN, EPI_NONE>(a, nWG, s); break;
+    case EPI_XPAY_DOT:     spmm_go<R, LM, LN, EPI_XPAY_DOT>(a, nWG, s); break;
+    case EPI_AXPY_NRM_DOT: spmm_go<R, LM, LN, EPI_AXPY_NRM_DOT>(a, nWG, s); break;
+    case EPI_RESIDUAL:     spmm_go<R, LM, LN, EPI_RESIDUAL>(a, nWG, s); break;
+    }
+}
+
+#define TFQ_SIZES(X, R) \
+    X(R, 4, 4) X(R, 4, 5) X(R, 4, 8) X(R, 4, 32) X(R, 8, 8) X(R, 8, 9) X(R, 8, 10) X(R, 8, 32) X(R, 8, 64) \
+    X(R, 16, 16) X(R, 16, 32) X(R, 16, 64) X(R, 32, 32) X(R, 32, 64) X(R, 64, 64)
+
+static bool spmm_dispatch(bool dbl, int lm, int ln, int epi, SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
+    int const key = lm * 1000 + ln;
+#define TFQ_CASE(R, LM, LN) case LM * 1000 + LN: spmm_epi<R, LM, LN>(epi, a, nWG, s); return true;
+    if (dbl) { switch (key) { TFQ_SIZES(TFQ_CASE, double) default: return false; } }
+    else     { switch (key) { TFQ_SIZES(TFQ_CASE, float)  default: return false; } }
+#undef TFQ_CASE
+}
+
+void spmm_launch(int epi, DevPlan const& d, hipStream_t s) {
+    SpmmArgs a{};
+    a.A = d.A; a.starts = d.starts; a.pairs = d.pairs; a.nY = d.nnzbX;
+    a.chunkFirst = d.chunkFirst; a.chunkCol = d.chunkCol; a.CH = 0;
+    a.ctl = d.ctl; a.v3 = d.v3; a.B = d.B; a.bOfX = d.bOfX; a.pz = d.pz; a.pd = d.pd;
+    switch (epi) {
+    case EPI_XPAY_DOT:     a.X = d.v6; a.Y = d.v9; a.e0 = d.v4; a.e1 = d.v8; a.sc = d.beta; a.gate = 1; break;
+    case EPI_AXPY_NRM_DOT: a.X = d.v6; a.Y = d.v8; a.e0 = d.v5; a.sc = d.alfa; a.gate = 1; break;
+    case EPI_RESIDUAL:     a.X = d.x;  a.Y = nullptr; a.gate = 2; break;
+    default: return;
+    }
+    spmm_dispatch(d.dbl, d.LM, d.LN, epi, a, d.nChunks, s);
+}
+
+tfqmrgpuStatus_t launch_multiply(char precision, int lm, int ln, uint32_t nnzbY,
+    uint32_t const* starts, uint32_t const* pairs, void const* A, void const* X, void* Y, hipStream_t s)
+{
+    bool const dbl = ('z' == (precision | 32)) || ('d' == (precision | 32));
+    SpmmArgs a{};
+    a.Y = Y; a.A = A; a.X = X; a.starts = starts; a.pairs = pairs; a.nY = nnzbY;
+    a.chunkFirst = nullptr; a.gate = 0;
+    // plain mode: enough work groups to fill 256 CUs several times, at least one strip per wave
+    bool const mfma = (lm % 16 == 0 && ln % 16 == 0);
+    int const mt = mfma ? lm / 16 : 1;
+    uint32_t ch = (mt >= 4) ? 1 : 4 / mt;                 // one 16-row strip per wave
+    if (!mfma) ch = (lm * ln >= 256) ? 1 : 256 / (lm * ln); // one Y block per thread group
+    a.CH = ch;
+    uint32_t const nWG = (nnzbY + ch - 1) / ch;
+    if (!spmm_dispatch(dbl, lm, ln, EPI_NONE, a, nWG, s))
+        return err(TFQMRGPU_BLOCKSIZE_MISSING, ln, lm);
+    return (hipSuccess == hipGetLastError()) ? TFQMRGPU_STATUS_SUCCESS : TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
+}
+
+} // namespace tfq

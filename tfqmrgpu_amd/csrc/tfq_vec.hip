@@ -1,0 +1,521 @@
+// Vector kernels of the tfQMR iteration for gfx950 (MI355X): fused complex AXPY/XPAY updates,
+// per-right-hand-side dot products / norms and the scalar Krylov coefficient updates.
+//
+// What is computed follows the reference operation by operation (real-space/tfQMRgpu
+// tfqmrgpu_core.hxx:189-233 for the sequence, tfqmrgpu_linalg.hxx:629-666 col_axpay,
+// :480-541 col_inner/col_reduction, :34-254 tfQMRdec35/34/T); how it is computed does not:
+//  * vectors are stored column-sorted, a work group owns a "chunk" = run of blocks of ONE block
+//    column, so the per-RHS scalars are loaded once per work group and reductions stay in
+//    registers until one [LN] record per chunk is written (no memset + tree of launches);
+//  * every lane moves 16 bytes per access (2 doubles / 4 floats) along the contiguous RHS index;
+//  * updates that the reference launches one by one are fused (each vector is read/written once
+//    between two scalar barriers);
+//  * reductions are deterministic: fixed shuffle-free LDS order inside a work group, fixed chunk
+//    order per column in the decision kernels.
+#include "tfq_device.hpp"
+#include "tfq_vec.hpp"
+
+namespace tfq {
+
+#define TFQ_EPS 2.5e-308   // breakdown threshold of the reference, tfqmrgpu_linalg.hxx:31
+
+// ---------------------------------------------------------------------------------------------------
+template <typename R> struct Vec;
+template <> struct Vec<double> { static constexpr int N = 2; using T = double2; };
+template <> struct Vec<float>  { static constexpr int N = 4; using T = float4;  };
+
+// largest thread count <= 256 such that a thread's elements keep their RHS index j on every trip
+template <int LN, int VEC> constexpr int activeThreads() {
+    int t = 256;
+    while ((t * VEC) % LN) --t;
+    return t;
+}
+
+template <typename R, int LM, int LN>
+struct Geo {
+    static constexpr int VEC = Vec<R>::N;
+    static constexpr int P = LM * LN;            // elements of one plane (Re or Im) of a block
+    static constexpr int IPB = P / VEC;          // vector items per block plane
+    static constexpr int T = activeThreads<LN, VEC>();
+    static_assert(P % VEC == 0, "block plane must be a multiple of the vector width");
+};
+
+template <typename R> __device__ inline void ldv(R (&r)[Vec<R>::N], R const* p) {
+    auto const v = *reinterpret_cast<typename Vec<R>::T const*>(p);
+    if constexpr (Vec<R>::N == 2) { r[0] = v.x; r[1] = v.y; } else { r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
+}
+template <typename R> __device__ inline void stv(R* p, R const (&r)[Vec<R>::N]) {
+    typename Vec<R>::T v;
+    if constexpr (Vec<R>::N == 2) { v.x = r[0]; v.y = r[1]; } else { v.x = r[0]; v.y = r[1]; v.z = r[2]; v.w = r[3]; }
+    *reinterpret_cast<typename Vec<R>::T*>(p) = v;
+}
+// the float shadow vector read with the vector width of R
+template <int N> __device__ inline void ldf(float (&r)[N], float const* p) {
+    if constexpr (N == 2) { auto const v = *reinterpret_cast<float2 const*>(p); r[0] = v.x; r[1] = v.y; }
+    else { auto const v = *reinterpret_cast<float4 const*>(p); r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
+}
+
+// per-thread copy of one complex scalar per owned RHS index
+template <typename R, int LN, int VEC>
+struct Scal {
+    R re[VEC], im[VEC];
+    __device__ inline void load(R const* a, uint32_t col, int t) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            int const j = (t * VEC + v) % LN;
+            re[v] = a[(size_t(col) * 2 + 0) * LN + j];
+            im[v] = a[(size_t(col) * 2 + 1) * LN + j];
+        }
+    }
+};
+
+// y := x + a*y  (reference expression order, tfqmrgpu_linalg.hxx:660-661)
+template <typename R> __device__ inline void xpay(R& yr, R& yi, R xr, R xi, R ar, R ai) {
+    R const nr = xr + ar * yr - ai * yi;
+    R const ni = xi + ai * yr + ar * yi;
+    yr = nr; yi = ni;
+}
+// y := a*x + y  (tfqmrgpu_linalg.hxx:656-657)
+template <typename R> __device__ inline void axpy(R& yr, R& yi, R xr, R xi, R ar, R ai) {
+    R const nr = ar * xr - ai * xi + yr;
+    R const ni = ai * xr + ar * xi + yi;
+    yr = nr; yi = ni;
+}
+
+// Sum the per-thread accumulators of a work group into out[NPL][LN] (one record per chunk).
+// Fixed order => bitwise reproducible.  s is LDS of NPL*256*VEC doubles.
+template <int LN, int VEC, int T, int NPL>
+__device__ inline void chunk_reduce(double (&acc)[NPL][VEC], double* s, double* out, int t) {
+    __syncthreads();
+    if (t < T) {
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) s[p * (256 * VEC) + t * VEC + v] = acc[p][v];
+    }
+    __syncthreads();
+    constexpr int terms = (T * VEC) / LN;
+    for (int e = t; e < NPL * LN; e += 256) {
+        int const p = e / LN, j = e % LN;
+        double sum = 0;
+        for (int n = 0; n < terms; ++n) sum += s[p * (256 * VEC) + n * LN + j];
+        out[p * LN + j] = sum;
+    }
+}
+
+#define TFQ_CHUNK_PROLOGUE(G)                                                     \
+    if (d.ctl->state != 0) return;                                                \
+    int const t = threadIdx.x;                                                    \
+    uint32_t const chunk = blockIdx.x;                                            \
+    uint32_t const first = d.chunkFirst[chunk];                                   \
+    uint32_t const nItems = (d.chunkFirst[chunk + 1] - first) * G::IPB;           \
+    uint32_t const col = d.chunkCol[chunk];                                       \
+    size_t const base = size_t(first) * 2 * G::P;                                 \
+    (void)col;
+
+#define TFQ_ITEM_OFFSETS(G)                                                       \
+    uint32_t const blk = w / G::IPB;                                              \
+    size_t const re = base + size_t(blk) * 2 * G::P + size_t(w - blk * G::IPB) * G::VEC; \
+    size_t const im = re + G::P;
+
+// ---- K0: pz <- v3 . v5 (unconjugated), start of a solve -------------------------------------------
+template <typename R, int LM, int LN>
+__global__ __launch_bounds__(256) void k_dot35(DevPlan d) {
+    using G = Geo<R, LM, LN>;
+    __shared__ double s[2 * 256 * G::VEC];
+    TFQ_CHUNK_PROLOGUE(G)
+    R const* v5 = (R const*)d.v5;
+    double acc[2][G::VEC] = {};
+    if (t < G::T) for (uint32_t w = t; w < nItems; w += G::T) {
+        TFQ_ITEM_OFFSETS(G)
+        R ar[G::VEC], ai[G::VEC]; float wr[G::VEC], wi[G::VEC];
+        ldv(ar, v5 + re); ldv(ai, v5 + im); ldf(wr, d.v3 + re); ldf(wi, d.v3 + im);
+#pragma unroll
+        for (int v = 0; v < G::VEC; ++v) {
+            double const xr = ar[v], xi = ai[v], yr = wr[v], yi = wi[v];
+            acc[0][v] += xr * yr - xi * yi;
+            acc[1][v] += xr * yi + xi * yr;
+        }
+    }
+    chunk_reduce<LN, G::VEC, G::T, 2>(acc, s, d.pz + size_t(chunk) * 2 * LN, t);
+}
+
+// ---- KA: v6 := v5 + beta v6 ------------------------------------------------------------------------
+template <typename R, int LM, int LN>
+__global__ __launch_bounds__(256) void k_xpay_v6(DevPlan d) {
+    using G = Geo<R, LM, LN>;
+    TFQ_CHUNK_PROLOGUE(G)
+    if (t >= G::T) return;
+    R const* v5 = (R const*)d.v5; R* v6 = (R*)d.v6;
+    Scal<R, LN, G::VEC> beta; beta.load((R const*)d.beta, col, t);
+    for (uint32_t w = t; w < nItems; w += G::T) {
+        TFQ_ITEM_OFFSETS(G)
+        R xr[G::VEC], xi[G::VEC], yr[G::VEC], yi[G::VEC];
+        ldv(xr, v5 + re); ldv(xi, v5 + im); ldv(yr, v6 + re); ldv(yi, v6 + im);
+#pragma unroll
+        for (int v = 0; v < G::VEC; ++v) xpay(yr[v], yi[v], xr[v], xi[v], beta.re[v], beta.im[v]);
+        stv(v6 + re, yr); stv(v6 + im, yi);
+    }
+}
+
+// ---- KC: v7 := v6 + c67 v7 ; v5 := alfa v9 + v5 ; pd <- |v5|^2 ----------------------------------------
+template <typename R, int LM, int LN>
+__global__ __launch_bounds__(256) void k_v7_v5_nrm(DevPlan d) {
+    using G = Geo<R, LM, LN>;
+    __shared__ double s[256 * G::VEC];
+    TFQ_CHUNK_PROLOGUE(G)
+    R const* v6 = (R const*)d.v6; R* v7 = (R*)d.v7; R* v5 = (R*)d.v5; R const* v9 = (R const*)d.v9;
+    double acc[1][G::VEC] = {};
+    if (t < G::T) {
+        Scal<R, LN, G::VEC> c67, alfa; c67.load((R const*)d.c67, col, t); alfa.load((R const*)d.alfa, col, t);
+        for (uint32_t w = t; w < nItems; w += G::T) {
+            TFQ_ITEM_OFFSETS(G)
+            R ar[G::VEC], ai[G::VEC], br[G::VEC], bi[G::VEC];
+            ldv(ar, v6 + re); ldv(ai, v6 + im); ldv(br, v7 + re); ldv(bi, v7 + im);
+#pragma unroll
+            for (int v = 0; v < G::VEC; ++v) xpay(br[v], bi[v], ar[v], ai[v], c67.re[v], c67.im[v]);
+            stv(v7 + re, br); stv(v7 + im, bi);
+            ldv(ar, v9 + re); ldv(ai, v9 + im); ldv(br, v5 + re); ldv(bi, v5 + im);
+#pragma unroll
+            for (int v = 0; v < G::VEC; ++v) {
+                axpy(br[v], bi[v], ar[v], ai[v], alfa.re[v], alfa.im[v]);
+                double const r = br[v], i = bi[v];
+                acc[0][v] += r * r + i * i;
+            }
+            stv(v5 + re, br); stv(v5 + im, bi);
+        }
+    }
+    chunk_reduce<LN, G::VEC, G::T, 1>(acc, s, d.pd + size_t(chunk) * LN, t);
+}
+
+// ---- KD: x := eta v7 + x ; v6 := alfa v4 + v6 ; v7 := v6 + c67 v7 ------------------------------------
+template <typename R, int LM, int LN>
+__global__ __launch_bounds__(256) void k_x_v6_v7(DevPlan d) {
+    using G = Geo<R, LM, LN>;
+    TFQ_CHUNK_PROLOGUE(G)
+    if (t >= G::T) return;
+    R* x = (R*)d.x; R* v6 = (R*)d.v6; R* v7 = (R*)d.v7; R const* v4 = (R const*)d.v4;
+    Scal<R, LN, G::VEC> eta, alfa, c67;
+    eta.load((R const*)d.eta, col, t); alfa.load((R const*)d.alfa, col, t); c67.load((R const*)d.c67, col, t);
+    for (uint32_t w = t; w < nItems; w += G::T) {
+        TFQ_ITEM_OFFSETS(G)
+        R sr[G::VEC], si[G::VEC], xr[G::VEC], xi[G::VEC], ar[G::VEC], ai[G::VEC], br[G::VEC], bi[G::VEC];
+        ldv(sr, v7 + re); ldv(si, v7 + im); ldv(xr, x + re); ldv(xi, x + im);
+        ldv(ar, v4 + re); ldv(ai, v4 + im); ldv(br, v6 + re); ldv(bi, v6 + im);
+#pragma unroll
+        for (int v = 0; v < G::VEC; ++v) {
+            axpy(xr[v], xi[v], sr[v], si[v], eta.re[v], eta.im[v]);       // x  += eta  v7
+            axpy(br[v], bi[v], ar[v], ai[v], alfa.re[v], alfa.im[v]);     // v6 += alfa v4
+            xpay(sr[v], si[v], br[v], bi[v], c67.re[v], c67.im[v]);       // v7  = v6 + c67 v7
+        }
+        stv(x + re, xr); stv(x + im, xi); stv(v6 + re, br); stv(v6 + im, bi); stv(v7 + re, sr); stv(v7 + im, si);
+    }
+}
+
+// ---- KF: x := eta v7 + x ---------------------------------------------------------------------------
+template <typename R, int LM, int LN>
+__global__ __launch_bounds__(256) void k_x(DevPlan d) {
+    using G = Geo<R, LM, LN>;
+    TFQ_CHUNK_PROLOGUE(G)
+    if (t >= G::T) return;
+    R* x = (R*)d.x; R const* v7 = (R const*)d.v7;
+    Scal<R, LN, G::VEC> eta; eta.load((R const*)d.eta, col, t);
+    for (uint32_t w = t; w < nItems; w += G::T) {
+        TFQ_ITEM_OFFSETS(G)
+        R sr[G::VEC], si[G::VEC], xr[G::VEC], xi[G::VEC];
+        ldv(sr, v7 + re); ldv(si, v7 + im); ldv(xr, x + re); ldv(xi, x + im);
+#pragma unroll
+        for (int v = 0; v < G::VEC; ++v) axpy(xr[v], xi[v], sr[v], si[v], eta.re[v], eta.im[v]);
+        stv(x + re, xr); stv(x + im, xi);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Column kernels: one work group per block column.  Sum the chunk records of the column in chunk
+// order (256/LN groups of LN lanes take every G-th record, then the groups are added in order),
+// then run the scalar update for the LN right-hand sides of the column.
+template <int LN, int NPL>
+__device__ inline void column_sum(double const* part, uint32_t c0, uint32_t c1, double* s, double (&res)[NPL]) {
+    constexpr int G = 256 / LN;
+    int const t = threadIdx.x, g = t / LN, j = t % LN;
+    double acc[NPL] = {};
+    if (g < G) for (uint32_t c = c0 + g; c < c1; c += G)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) acc[p] += part[(size_t(c) * NPL + p) * LN + j];
+    __syncthreads();
+    if (g < G)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) s[(g * NPL + p) * LN + j] = acc[p];
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) res[p] = 0;
+    if (t < LN) for (int gg = 0; gg < G; ++gg)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) res[p] += s[(gg * NPL + p) * LN + t];
+}
+
+// dec35: beta = z/rho, rho = z  (tfqmrgpu_linalg.hxx:50-75)
+template <typename R, int LN>
+__global__ __launch_bounds__(256) void k_dec35(DevPlan d) {
+    if (d.ctl->state != 0) return;
+    __shared__ double s[256 * 2];
+    uint32_t const col = blockIdx.x;
+    double z[2];
+    column_sum<LN, 2>(d.pz, d.colChunkPtr[col], d.colChunkPtr[col + 1], s, z);
+    int const j = threadIdx.x;
+    if (j >= LN) return;
+    size_t const ir = (size_t(col) * 2 + 0) * LN + j, ii = ir + LN;
+    R* rho = (R*)d.rho; R* bet = (R*)d.beta;
+    double const rr = double(rho[ir]), ri = double(rho[ii]);
+    double const abs2rho = rr * rr + ri * ri, abs2z = z[0] * z[0] + z[1] * z[1];
+    d.z[ir] = z[0]; d.z[ii] = z[1];
+    if (abs2z < TFQ_EPS || abs2rho < TFQ_EPS) {
+        d.status[size_t(col) * LN + j] = -1;
+        bet[ir] = 0; bet[ii] = 0; rho[ir] = 0; rho[ii] = 0;
+    } else {
+        double const den = 1. / abs2rho;
+        bet[ir] = R((z[0] * rr + z[1] * ri) * den);
+        bet[ii] = R((z[1] * rr - z[0] * ri) * den);
+        rho[ir] = R(z[0]); rho[ii] = R(z[1]);
+    }
+}
+
+// dec34: alfa = -rho/z, c67 = z*(var*eta/rho)  (tfqmrgpu_linalg.hxx:116-151)
+template <typename R, int LN>
+__global__ __launch_bounds__(256) void k_dec34(DevPlan d) {
+    if (d.ctl->state != 0) return;
+    __shared__ double s[256 * 2];
+    uint32_t const col = blockIdx.x;
+    double z[2];
+    column_sum<LN, 2>(d.pz, d.colChunkPtr[col], d.colChunkPtr[col + 1], s, z);
+    int const j = threadIdx.x;
+    if (j >= LN) return;
+    size_t const ir = (size_t(col) * 2 + 0) * LN + j, ii = ir + LN;
+    R const* rho = (R const*)d.rho; R const* eta = (R const*)d.eta; R* alf = (R*)d.alfa; R* c67 = (R*)d.c67;
+    double const rr = double(rho[ir]), ri = double(rho[ii]);
+    double const abs2rho = rr * rr + ri * ri, abs2z = z[0] * z[0] + z[1] * z[1];
+    d.z[ir] = z[0]; d.z[ii] = z[1];
+    if (abs2z < TFQ_EPS || abs2rho < TFQ_EPS) {
+        d.status[size_t(col) * LN + j] = -2;
+        alf[ir] = 0; alf[ii] = 0; c67[ir] = 0; c67[ii] = 0;
+    } else {
+        double const er = double(eta[ir]), ei = double(eta[ii]);
+        double const zden = -1. / abs2z;
+        alf[ir] = R((rr * z[0] + ri * z[1]) * zden);
+        alf[ii] = R((ri * z[0] - rr * z[1]) * zden);
+        double const vden = d.var[size_t(col) * LN + j] / abs2rho;
+        double const tr = (er * rr + ei * ri) * vden, ti = (ei * rr - er * ri) * vden;
+        c67[ir] = R(z[0] * tr - z[1] * ti);
+        c67[ii] = R(z[1] * tr + z[0] * ti);
+    }
+}
+
+// decT: var = d/tau, c = 1/(1+var), tau = d c, eta = -c alfa [, c67 = var c]  (tfqmrgpu_linalg.hxx:195-229)
+// FINAL additionally leaves the per-column record for the stopping test:
+//   colrec[col] = { max_j tau_j/|b_j|^2 , 1 if any RHS of the column is not broken down (-1/-2) }
+template <typename R, int LN, bool SETC67, bool FINAL>
+__global__ __launch_bounds__(256) void k_decT(DevPlan d) {
+    if (d.ctl->state != 0) return;
+    __shared__ double s[256];
+    __shared__ double rec[2][LN];
+    uint32_t const col = blockIdx.x;
+    double dd[1];
+    column_sum<LN, 1>(d.pd, d.colChunkPtr[col], d.colChunkPtr[col + 1], s, dd);
+    int const j = threadIdx.x;
+    if (j < LN) {
+        size_t const ir = (size_t(col) * 2 + 0) * LN + j, ii = ir + LN, i1 = size_t(col) * LN + j;
+        R const* alf = (R const*)d.alfa; R* eta = (R*)d.eta; R* c67 = (R*)d.c67;
+        double cosi = 0; R r67 = 1;
+        double const Tau = d.tau[i1];
+        int8_t st = d.status[i1];
+        double newTau;
+        if (fabs(Tau) > TFQ_EPS) {
+            double const Var = dd[0] / Tau;
+            cosi = 1. / (1. + Var);
+            d.var[i1] = Var;
+            newTau = dd[0] * cosi;
+            r67 = R(Var * cosi);
+        } else {
+            st = -3; d.status[i1] = -3;
+            d.var[i1] = 0; newTau = 0;
+        }
+        d.tau[i1] = newTau;
+        d.d[i1] = dd[0];
+        if (st < 0) { eta[ir] = 0; eta[ii] = 0; }
+        else { eta[ir] = R(-cosi * alf[ir]); eta[ii] = R(-cosi * alf[ii]); }
+        if (SETC67) { c67[ir] = r67; c67[ii] = 0; }
+        if (FINAL) { rec[0][j] = newTau * d.invBn2[i1]; rec[1][j] = (st == -1 || st == -2) ? 0. : 1.; }
+    }
+    if (FINAL) {
+        __syncthreads();
+        if (0 == j) {
+            double mx = 0, alive = 0; // max ignores NaN like std::max(a, nan) == a in the reference loop
+            for (int jj = 0; jj < LN; ++jj) { if (rec[0][jj] > mx) mx = rec[0][jj]; if (rec[1][jj] > alive) alive = rec[1][jj]; }
+            d.colrec[size_t(col) * 2 + 0] = mx; d.colrec[size_t(col) * 2 + 1] = alive;
+        }
+    }
+}
+
+// true residual per RHS of one column after the probe multiply (tfqmrgpu_core.hxx:274-286):
+//   colrec[col] = { max_j res2_j , 1 if any RHS with status 0 has res2 > tol2 }
+template <int LN>
+__global__ __launch_bounds__(256) void k_probe_col(DevPlan d) {
+    if (d.ctl->state != 0 || d.ctl->probe == 0) return;
+    __shared__ double s[256];
+    __shared__ double rec[2][LN];
+    uint32_t const col = blockIdx.x;
+    double dd[1];
+    column_sum<LN, 1>(d.pd, d.colChunkPtr[col], d.colChunkPtr[col + 1], s, dd);
+    int const j = threadIdx.x;
+    if (j < LN) {
+        size_t const i1 = size_t(col) * LN + j;
+        double const res2 = dd[0] * d.invBn2[i1];
+        double const tol2 = d.ctl->tol2;
+        double open = 0;
+        if (res2 > tol2) { if (0 == d.status[i1]) open = 1; }
+        else if (res2 <= 0) d.status[i1] = 1;
+        rec[0][j] = res2; rec[1][j] = open;
+    }
+    __syncthreads();
+    if (0 == j) {
+        double mx = 0, open = 0;
+        for (int jj = 0; jj < LN; ++jj) { if (rec[0][jj] > mx) mx = rec[0][jj]; if (rec[1][jj] > open) open = rec[1][jj]; }
+        d.colrec[size_t(col) * 2 + 0] = mx; d.colrec[size_t(col) * 2 + 1] = open;
+    }
+}
+
+// ---- single work group: max over the column records, then the stopping decision -------------------
+// what = 0: end of an iteration (tfqmrgpu_core.hxx:239-260), 1: after a probe (:287-298)
+// phase 0: reduce + decide, 1: reduce only into ctl->red (an all-reduce follows), 2: decide only
+__global__ __launch_bounds__(256) void k_decide(DevPlan d, int what, int phase) {
+    Ctl* c = d.ctl;
+    if (c->state != 0) return;
+    if (1 == what && 0 == c->probe) return;
+    __shared__ double s0[256], s1[256];
+    int const t = threadIdx.x;
+    if (phase != 2) {
+        double a = 0, b = 0;
+        for (uint32_t col = t; col < d.nCols; col += 256) {
+            double const u = d.colrec[size_t(col) * 2], v = d.colrec[size_t(col) * 2 + 1];
+            if (u > a) a = u; if (v > b) b = v;
+        }
+        s0[t] = a; s1[t] = b;
+        __syncthreads();
+        for (int h = 128; h > 0; h >>= 1) {
+            if (t < h) { if (s0[t + h] > s0[t]) s0[t] = s0[t + h]; if (s1[t + h] > s1[t]) s1[t] = s1[t + h]; }
+            __syncthreads();
+        }
+        if (0 == t) { c->red[2 * what] = s0[0]; c->red[2 * what + 1] = s1[0]; }
+        __syncthreads();
+    }
+    if (phase == 1 || t != 0) return;
+    if (0 == what) {
+        int const it = ++c->iteration;
+        double const bound2 = c->red[0] * (2 * it + 1);
+        c->max_bound2 = bound2;
+        int probe = (bound2 <= c->target_bound2) || (it >= c->maxIterations);
+        if (c->red[1] == 0.) { c->state = 2; probe = 0; } // every right-hand side broke down
+        c->probe = probe;
+    } else {
+        double max_res2 = 1.4e-76;
+        if (c->red[2] > max_res2) max_res2 = c->red[2];
+        c->residual2_reached = max_res2;
+        c->target_bound2 = (c->max_bound2 / max_res2) * c->tol2;
+        c->nprobes += 1;
+        c->probe = 0;
+        if (c->red[3] == 0.) { c->iterations_needed = c->iteration; c->state = 1; }
+        else if (c->iteration >= c->maxIterations) c->state = 3;
+    }
+}
+
+// ---- start of a solve ---------------------------------------------------------------------------
+// v5[subset[b]] := B[b]   (add_RHS onto the cleared v5, tfqmrgpu_core.hxx:153)
+template <typename R, int LM, int LN>
+__global__ __launch_bounds__(256) void k_scatter_B(DevPlan d) {
+    constexpr int E = 2 * LM * LN;
+    uint32_t const b = blockIdx.x;
+    R const* src = (R const*)d.B + size_t(b) * E;
+    R* dst = (R*)d.v5 + size_t(d.subset[b]) * E;
+    for (int e = threadIdx.x; e < E; e += 256) dst[e] = src[e];
+}
+
+// tau := |b|^2 per RHS, 1/|b|^2, rho := 1, everything else 0 (tfqmrgpu_core.hxx:121-127,154-166)
+template <typename R, int LM, int LN>
+__global__ __launch_bounds__(256) void k_init_col(DevPlan d, double tol, int maxIterations) {
+    constexpr int P = LM * LN;
+    __shared__ double s[256];
+    uint32_t const col = blockIdx.x;
+    int const t = threadIdx.x;
+    constexpr int G = 256 / LN;
+    int const g = t / LN, j = t % LN;
+    double acc = 0;
+    if (g < G) for (uint32_t q = d.bColPtr[col]; q < d.bColPtr[col + 1]; ++q) { // blocks of B in column order
+        R const* b = (R const*)d.B + size_t(d.bList[q]) * 2 * P;
+        for (int i = g; i < LM; i += G) {
+            double const r = b[i * LN + j], im = b[P + i * LN + j];
+            acc += r * r + im * im;
+        }
+    }
+    if (g < G) s[g * LN + j] = acc;
+    __syncthreads();
+    if (t < LN) {
+        double n2 = 0;
+        for (int gg = 0; gg < G; ++gg) n2 += s[gg * LN + t];
+        size_t const ir = (size_t(col) * 2 + 0) * LN + t, ii = ir + LN, i1 = size_t(col) * LN + t;
+        d.tau[i1] = n2; d.invBn2[i1] = 1. / n2; d.var[i1] = 0; d.d[i1] = 0; d.status[i1] = 0;
+        ((R*)d.rho)[ir] = 1; ((R*)d.rho)[ii] = 0;
+        ((R*)d.alfa)[ir] = 0; ((R*)d.alfa)[ii] = 0; ((R*)d.beta)[ir] = 0; ((R*)d.beta)[ii] = 0;
+        ((R*)d.c67)[ir] = 0; ((R*)d.c67)[ii] = 0; ((R*)d.eta)[ir] = 0; ((R*)d.eta)[ii] = 0;
+    }
+    if (0 == col && 0 == t) {
+        Ctl* c = d.ctl;
+        double const tol2 = tol * tol;
+        c->tol2 = tol2; c->target_bound2 = tol2 * 100 * 100; c->max_bound2 = 0; c->residual2_reached = 1e300;
+        c->red[0] = c->red[1] = c->red[2] = c->red[3] = 0;
+        c->iteration = 0; c->maxIterations = maxIterations;
+        c->state = (maxIterations > 0) ? 0 : 3;
+        c->probe = 0; c->iterations_needed = maxIterations; c->nprobes = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+#define TFQ_SIZES(X, R) \
+    X(R, 4, 4) X(R, 4, 5) X(R, 4, 8) X(R, 4, 32) X(R, 8, 8) X(R, 8, 9) X(R, 8, 10) X(R, 8, 32) X(R, 8, 64) \
+    X(R, 16, 16) X(R, 16, 32) X(R, 16, 64) X(R, 32, 32) X(R, 32, 64) X(R, 64, 64)
+
+template <typename R, int LM, int LN>
+static void vec_run(int op, DevPlan const& d, double tol, int maxIt, hipStream_t s) {
+    dim3 const grid(d.nChunks), cols(d.nCols), blk(256);
+    switch (op) {
+    case VEC_SETUP: {
+        size_t const S = size_t(d.nnzbX) * 2 * LM * LN * sizeof(R);
+        // x, v4..v9 are contiguous in the buffer (x first): clear them with one async memset
+        (void)hipMemsetAsync(d.x, 0, size_t((char*)d.v9 - (char*)d.x) + S, s);
+        if (d.nnzbB) k_scatter_B<R, LM, LN><<<dim3(d.nnzbB), blk, 0, s>>>(d);
+        k_init_col<R, LM, LN><<<cols, blk, 0, s>>>(d, tol, maxIt);
+        k_dot35<R, LM, LN><<<grid, blk, 0, s>>>(d);
+    } break;
+    case VEC_DEC35:    k_dec35<R, LN><<<cols, blk, 0, s>>>(d); break;
+    case VEC_XPAY_V6:  k_xpay_v6<R, LM, LN><<<grid, blk, 0, s>>>(d); break;
+    case VEC_DEC34:    k_dec34<R, LN><<<cols, blk, 0, s>>>(d); break;
+    case VEC_V7_V5:    k_v7_v5_nrm<R, LM, LN><<<grid, blk, 0, s>>>(d); break;
+    case VEC_DECT_C67: k_decT<R, LN, true, false><<<cols, blk, 0, s>>>(d); break;
+    case VEC_X_V6_V7:  k_x_v6_v7<R, LM, LN><<<grid, blk, 0, s>>>(d); break;
+    case VEC_DECT_FIN: k_decT<R, LN, false, true><<<cols, blk, 0, s>>>(d); break;
+    case VEC_X:        k_x<R, LM, LN><<<grid, blk, 0, s>>>(d); break;
+    case VEC_PROBE_COL: k_probe_col<LN><<<cols, blk, 0, s>>>(d); break;
+    }
+}
+
+void vec_launch(int op, DevPlan const& d, double tol, int maxIt, hipStream_t s) {
+    int const key = d.LM * 1000 + d.LN;
+#define TFQ_CASE(R, LM, LN) case LM * 1000 + LN: vec_run<R, LM, LN>(op, d, tol, maxIt, s); break;
+    if (d.dbl) { switch (key) { TFQ_SIZES(TFQ_CASE, double) default: break; } }
+    else       { switch (key) { TFQ_SIZES(TFQ_CASE, float)  default: break; } }
+#undef TFQ_CASE
+}
+
+void launch_decide(DevPlan const& d, int phase, hipStream_t s)       { k_decide<<<1, 256, 0, s>>>(d, 0, phase); }
+void launch_probe_decide(DevPlan const& d, int phase, hipStream_t s) { k_decide<<<1, 256, 0, s>>>(d, 1, phase); }
+
+} // namespace tfq

@@ -1,0 +1,25 @@
+// internal launch interface of the vector / column kernels (tfq_vec.hip) and the multiply (tfq_spmm.hip)
+#pragma once
+#include "tfq_device.hpp"
+
+namespace tfq {
+
+enum {
+    VEC_SETUP = 0,     // clear vectors, v5 := B, tau := |b|^2, rho := 1, pz <- v3.v5
+    VEC_DEC35,         // beta, rho from pz
+    VEC_XPAY_V6,       // v6 := v5 + beta v6
+    VEC_DEC34,         // alfa, c67 from pz
+    VEC_V7_V5,         // v7 := v6 + c67 v7 ; v5 += alfa v9 ; pd <- |v5|^2
+    VEC_DECT_C67,      // tau, var, eta, c67 from pd
+    VEC_X_V6_V7,       // x += eta v7 ; v6 += alfa v4 ; v7 := v6 + c67 v7
+    VEC_DECT_FIN,      // tau, var, eta from pd + per-column stopping record
+    VEC_X,             // x += eta v7
+    VEC_PROBE_COL      // per-column residual record from pd
+};
+
+void vec_launch(int op, DevPlan const& d, double tol, int maxIt, hipStream_t s);
+
+// Y = A*X over the plan's pair list with a fused epilogue (EPI_* in tfq_device.hpp)
+void spmm_launch(int epi, DevPlan const& d, hipStream_t s);
+
+} // namespace tfq
