@@ -38,7 +38,13 @@ def lib():
         _lib = C.CDLL(ORACLE_SO)
         _lib.tfqo_shadow_glibc.argtypes = [C.c_void_p, C.c_uint64]
         _lib.tfqo_shadow_glibc.restype = None
+        # a GPU box shows far more hardware threads than its CPU share: never let OpenMP grab them all
+        set_threads(min(8, os.cpu_count() or 1))
     return _lib
+
+
+def set_threads(n):
+    return _lib.tfqo_set_threads(C.c_int(n))
 
 
 def have_ref():

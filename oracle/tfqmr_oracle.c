@@ -25,6 +25,21 @@
 
 typedef void (*tfqo_reduce_t)(void *ctx, double *values, int n);
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* threads used by the multiply (the only parallel loop; the reference's solver is single threaded,
+ * only its benchmark's check loop uses OpenMP, bench_tfqmrgpu.cu:358-365).  Returns the count in use. */
+int tfqo_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n; return 1;
+#endif
+}
+
 /* ---- integer analysis: restates tfqmrgpu_bsrsv_createPlan (tfqmrgpu.cu:161-339) --------------
  * Outputs (all 0-based, caller allocates):
  *   starts[nnzbX+1], pairs[2*capPairs], subset[nnzbB], colindx[nnzbX], origcol[<= nnzbX]

@@ -69,6 +69,13 @@ def load_library(path=LIB_PATH):
         raise ImportError(
             "tfqmrgpu_amd: %s is missing -- the HIP library has not been built; there is no CPU fallback. "
             "Run __graft_entry__.build() or `make -C tfqmrgpu_amd/csrc`." % path)
+    # PyTorch ships its own libamdhip64.so.7 (same soname as /opt/rocm's).  A process must run ONE HIP
+    # runtime: when torch is going to be used (bench.py, tests: device memory, streams, torch.distributed)
+    # it has to be loaded first, then this library binds to the runtime that is already there.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     I, P = C.c_int, C.c_void_p
     lib.tfqmrgpuGetErrorString.restype = C.c_char_p
