@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: tfQMR solves of a block-sparse system through the C-ABI of libtfQMRgpu.so.
+
+Workload (BASELINE.json configs[1]): the finite-difference example `generate_FD_example 16 120 4 2 -0.25`
+(2-D, block edge 4 -> 16x16 complex<double> blocks; mb=3573, nnzbA=17589, nnzbX=138229, 49 block
+columns = 784 right-hand sides, 679189 block products per multiply), solved to 1e-9.
+A "step" is one complete solve (setup, all iterations with both multiplies, residual probes); the
+matrices are resident in HBM before the timed region.  `value` = reference flop count of the solves
+(tfqmrgpu_bsrsv_getInfo, the number the reference's own `bench_tfqmrgpu tfQMR` divides by its solver
+time, bench_tfqmrgpu.cu:200-204) / wall time, summed over all GPUs.
+
+--gpus N (launched by torch.distributed.run, one process per GPU): weak scaling, every rank owns its own
+49 block columns of a N*49-column system (same A, same sparsity, own shadow vector); the only
+communication is the RCCL max-all-reduce of the stopping-test scalars inside the solver.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0                          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}  # dense matrix peaks (f64: SURVEY.md 8d public spec, f32: guide)
+
+
+def build_problem(name, rank):
+    from tfqmrgpu_amd import problems as PR
+    from tfqmrgpu_amd.fd_generator import FDExample
+    if name == "fd2d_16x16_z":
+        ex = FDExample(16, 120, 4, 2, -0.25, 4)
+        pr, prec, desc = ex.problem(), "z", "generate_FD_example 16 120 4 2 -0.25 n 0 4 (16x16 complex<double>)"
+    elif name == "fd2d_16x16_z_small":
+        ex = FDExample(6, 24, 4, 2, -0.25, 4)
+        pr, prec, desc = ex.problem(), "z", "generate_FD_example 6 24 4 2 -0.25 n 0 4 (16x16 complex<double>)"
+    elif name == "stencil3d_32x32_c":   # BASELINE configs[2]: 32x32 complex<float>, ~50k A blocks, 64 RHS
+        pr = PR.stencil_2d(64, 64, 32, 32, 2, seed=3, points=13)
+        pr.tolerance = 1e-4
+        prec, desc = "c", "13-point block stencil 64x64, 32x32 complex<float>, 2 block columns (64 RHS)"
+    elif name == "stencil2d_8x8_z":     # BASELINE configs[4]: 8x8 complex<double>, ~5 nnz/row
+        pr = PR.stencil_2d(256, 256, 8, 8, 8, seed=5)
+        prec, desc = "z", "5-point block stencil 256x256, 8x8 complex<double>, 8 block columns"
+    else:
+        raise SystemExit("unknown workload " + name)
+    ncols = int(pr.colIndX.max()) + 1
+    if rank:  # this rank's block columns of the global system
+        pr.colIndX = pr.colIndX + rank * ncols
+        pr.colIndB = pr.colIndB + rank * ncols
+    return pr, prec, desc
+
+
+def kernel_model(pr, prec, nPairs, nA_ref):
+    """algorithmic bytes and flops per launch of each kernel class of one iteration"""
+    rb = 8 if prec == "z" else 4
+    S = pr.nnzbX * 2 * pr.LM * pr.LN * rb            # one X-shaped vector
+    S3 = pr.nnzbX * 2 * pr.LM * pr.LN * 4            # the float shadow vector
+    A = nA_ref * 2 * pr.LM * pr.LM * rb
+    idx = 4 * (pr.nnzbX + 1) + 8 * nPairs
+    fm = nPairs * 8.0 * pr.LM * pr.LM * pr.LN
+    el = pr.nnzbX * pr.LM * pr.LN
+    return {
+        "xpay_v6": (3 * S, 8.0 * el),
+        "spmm_v4_dot": (5 * S + S3 + A + idx, fm + 24.0 * el),
+        "v7_v5_nrm": (6 * S, 20.0 * el),
+        "x_v6_v7": (7 * S, 24.0 * el),
+        "spmm_v5_nrm_dot": (4 * S + S3 + A + idx, fm + 20.0 * el),
+        "x": (3 * S, 8.0 * el),
+        "multiply": (2 * S + A + idx, fm),
+    }
+
+
+def roof(bytes_, flops, ms, prec):
+    peak_f = MFMA_PEAK_TFLOPS["f64" if prec == "z" else "f32"]
+    t_b, t_f = bytes_ / (HBM_PEAK_GBS * 1e9), flops / (peak_f * 1e12)
+    gbs, tfs = bytes_ / (ms * 1e-3) / 1e9, flops / (ms * 1e-3) / 1e12
+    if t_b >= t_f:
+        return dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4), tflops=round(tfs, 3))
+    return dict(bound="mfma", achieved=round(tfs, 3), peak=peak_f, unit="TFLOP/s", frac=round(tfs / peak_f, 4), gbs=round(gbs, 1))
+
+
+def cpu_baseline(pr, prec, threads):
+    """the CPU oracle (port of the reference CPU path) on a bounded sample: ONE tfQMR iteration + final probe
+    (3 block-sparse multiplies + all vector ops) of the same system"""
+    from oracle import pyoracle as O
+    O.lib()
+    used = O.set_threads(threads)
+    an = O.analyse(pr)
+    t0 = time.time()
+    st, X, info = O.solve(pr, prec, threshold=pr.tolerance, max_iterations=1, plan=an)
+    dt = time.time() - t0
+    return dict(value=round(info["flops"] / dt / 1e12, 6), unit="TFLOP/s", cores=used, kind="port",
+                sample="1 tfQMR iteration + residual probe (3 of the BSR multiplies, all vector ops) of the same system: "
+                       "%.2f GFlop in %.2f s; multiply threaded with OpenMP, vector ops single-threaded like the reference"
+                       % (info["flops"] / 1e9, dt),
+                seconds=round(dt, 3))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="fd2d_16x16_z")
+    ap.add_argument("--max-iterations", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--multiply-reps", type=int, default=20)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import tfqmrgpu_amd as T
+    pr, prec, desc = build_problem(args.workload, rank)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        s = T.Solver(stream.cuda_stream)
+        s.create_plan(pr)
+        view = s.plan_view()
+        nbytes = s.buffer_size(pr.LM, pr.LN, prec)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        s.set_buffer(device_ptr=buf.data_ptr())
+        s.set_matrix("A", pr.A)
+        s.set_matrix("B", pr.B)
+        if world > 1:  # RCCL communicator of the stopping test: id from rank 0, broadcast with torch.distributed
+            uid = (C.c_char * 128)()
+            if rank == 0:
+                T._check(T.lib.tfqmrgpuExt_commUniqueId(uid), "tfqmrgpuExt_commUniqueId")
+            t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device="cuda")
+            dist.broadcast(t, 0)
+            uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
+            T._check(T.lib.tfqmrgpuExt_commInit(s.handle, world, rank, uid), "tfqmrgpuExt_commInit")
+
+        def barrier():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize()
+
+        for _ in range(args.warmup):
+            st = s.solve(pr.tolerance, args.max_iterations)
+        s.set_profiling(True)
+        prof = {}
+        flops = iters = 0
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            st = s.solve(pr.tolerance, args.max_iterations)
+            info = s.get_info()
+            flops += info["flops"]
+            iters += info["iterations"]
+            for k, (n, ms) in s.profile().items():
+                a = prof.setdefault(k, [0, 0.0])
+                a[0] += n
+                a[1] += ms
+        barrier()
+        elapsed = time.perf_counter() - t0
+        s.set_profiling(False)
+        if world > 1:
+            red = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(red, op=dist.ReduceOp.MAX)
+            elapsed = float(red.item())
+            tot = torch.tensor([flops, float(iters)], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            flops, iters_all = float(tot[0].item()), float(tot[1].item())
+        else:
+            iters_all = float(iters)
+
+        out = None
+        if rank == 0:
+            nPairs = view["nPairs"]
+            nA_ref = len(np.unique(view["pairs"][0::2]))
+            model = kernel_model(pr, prec, nPairs, nA_ref)
+            per_kernel = {k: dict(launches=n, avg_ms=round(ms / n, 5), total_ms=round(ms, 3)) for k, (n, ms) in prof.items() if n}
+            dom = max((k for k in per_kernel if k in model), key=lambda k: per_kernel[k]["total_ms"])
+            rl = roof(model[dom][0], model[dom][1], per_kernel[dom]["avg_ms"], prec)
+            rl.update(kernel=dom, avg_ms=per_kernel[dom]["avg_ms"], launches=per_kernel[dom]["launches"],
+                      algorithmic_bytes=int(model[dom][0]), algorithmic_flops=float(model[dom][1]), traffic=None)
+            tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tp):
+                rl["traffic"] = json.load(open(tp)).get(args.workload, {}).get(dom)
+
+            # the stand-alone multiply on the same pair list (what the reference times in `bench_tfqmrgpu multi`)
+            real = torch.float64 if prec == "z" else torch.float32
+            An = torch.from_numpy(np.ascontiguousarray(np.stack([pr.A.transpose(0, 2, 1).real, pr.A.transpose(0, 2, 1).imag], axis=1))).to(real).cuda()
+            Xn = torch.rand((pr.nnzbX, 2, pr.LM, pr.LN), dtype=real, device="cuda") * 2 - 1
+            Yn = torch.empty_like(Xn)
+            dS = torch.from_numpy(view["starts"].view(np.int32)).cuda()
+            dP = torch.from_numpy(view["pairs"].view(np.int32)).cuda()
+
+            def mult():
+                T._check(T.lib.tfqmrgpuExt_multiply(s.handle, prec.encode(), pr.LM, pr.LN, pr.nnzbX, dS.data_ptr(), dP.data_ptr(),
+                                                    An.data_ptr(), Xn.data_ptr(), Yn.data_ptr()), "tfqmrgpuExt_multiply")
+            for _ in range(3):
+                mult()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(args.multiply_reps):
+                mult()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            mms = e0.elapsed_time(e1) / args.multiply_reps
+            rm = roof(model["multiply"][0], model["multiply"][1], mms, prec)
+            rm.update(kernel="multiply (Y = A*X, no epilogue)", avg_ms=round(mms, 5), launches=args.multiply_reps,
+                      algorithmic_bytes=int(model["multiply"][0]), algorithmic_flops=float(model["multiply"][1]))
+
+            S = pr.nnzbX * 2 * pr.LM * pr.LN * (8 if prec == "z" else 4)
+            it_bytes = sum(model[k][0] for k in ("xpay_v6", "spmm_v4_dot", "v7_v5_nrm", "x_v6_v7", "spmm_v5_nrm_dot", "x"))
+            it_ms = sum(v["total_ms"] for k, v in per_kernel.items() if k != "probe") / max(1, iters)
+            out = {
+                "metric": "tfQMR solve throughput to 1e-9 residual (reference flop count / solve time); iterations/s and BSR multiply GB/s + TFLOP/s in extra keys",
+                "value": round(flops / elapsed / 1e12, 4), "unit": "TFLOP/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f64" if prec == "z" else "f32", "data": "synthetic",
+                "config": {"workload": desc, "name": args.workload, "mb": pr.mb, "nnzbA": pr.nnzbA, "nnzbX_per_gpu": pr.nnzbX,
+                           "block_columns_per_gpu": view["nCols"], "rhs_per_gpu": view["nCols"] * pr.LN, "pairs": nPairs,
+                           "threshold": pr.tolerance, "sharding": "block columns of X/B per GPU, RCCL max-all-reduce of the stopping test"},
+                "iterations_per_solve": iters / args.steps,
+                "iterations_per_second": round(iters_all / world / elapsed, 2),
+                "rhs_iterations_per_second": round(iters_all * view["nCols"] * pr.LN / elapsed, 1),
+                "solve_status": int(st), "residual": info["residual"],
+                "buffer_GB_per_gpu": round(nbytes / 1e9, 3), "vector_MB": round(S / 1e6, 1),
+                "roofline": rl,
+                "roofline_multiply": rm,
+                "roofline_iteration": dict(bound="hbm", achieved=round(it_bytes / (it_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                                           frac=round(it_bytes / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), ms_per_iteration=round(it_ms, 4),
+                                           algorithmic_bytes=int(it_bytes)),
+                "kernels": per_kernel,
+            }
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(pr, prec, min(16, os.cpu_count() or 1))
+        s.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -30,7 +30,8 @@ EXPORTED_SYMBOLS = [  # include/tfqmrgpu.h
     "tfqmrgpu_bsrsv_solve", "tfqmrgpu_bsrsv_getInfo", "tfqmrgpu_bsrsv_z", "tfqmrgpu_bsrsv_c",
 ]
 EXT_SYMBOLS = [  # include/tfqmrgpu_ext.h
-    "tfqmrgpuExt_planView", "tfqmrgpuExt_getBoundHistory", "tfqmrgpuExt_setShadowMode",
+    "tfqmrgpuExt_planView", "tfqmrgpuExt_getBoundHistory", "tfqmrgpuExt_setProfiling", "tfqmrgpuExt_getProfile",
+    "tfqmrgpuExt_setShadowMode",
     "tfqmrgpuExt_setShadowVector", "tfqmrgpuExt_multiply", "tfqmrgpuExt_shardColumns",
     "tfqmrgpuExt_freeShard", "tfqmrgpuExt_commUniqueId", "tfqmrgpuExt_commInit",
     "tfqmrgpuExt_commDestroy", "tfqmrgpuExt_setReduceCallback",
@@ -104,6 +105,8 @@ def load_library(path=LIB_PATH):
     lib.tfqmrgpu_bsrsv_c.argtypes = onecall
     lib.tfqmrgpuExt_planView.argtypes = [P, C.POINTER(PlanView)]
     lib.tfqmrgpuExt_getBoundHistory.argtypes = [P, P, C.c_int32]
+    lib.tfqmrgpuExt_setProfiling.argtypes = [P, I]
+    lib.tfqmrgpuExt_getProfile.argtypes = [P, P, P]
     lib.tfqmrgpuExt_setShadowMode.argtypes = [P, I]
     lib.tfqmrgpuExt_setShadowVector.argtypes = [P, P, P]
     lib.tfqmrgpuExt_multiply.argtypes = [P, C.c_char, I, I, C.c_uint32, P, P, P, P, P]
@@ -267,6 +270,19 @@ class Solver:
         if n > 0:
             lib.tfqmrgpuExt_getBoundHistory(self.plan, _ptr(h), n)
         return h
+
+    PROFILE_CLASSES = ["dec35", "xpay_v6", "spmm_v4_dot", "dec34", "v7_v5_nrm", "decT_c67", "x_v6_v7",
+                       "spmm_v5_nrm_dot", "decT_final", "x", "decide", "probe"]
+
+    def set_profiling(self, on=True):
+        _check(lib.tfqmrgpuExt_setProfiling(self.plan, int(on)), "tfqmrgpuExt_setProfiling")
+
+    def profile(self):
+        """{kernel class: (launches, total ms)} of the last solve"""
+        n = len(self.PROFILE_CLASSES)
+        cnt, ms = np.zeros(n, np.int64), np.zeros(n, np.float64)
+        _check(lib.tfqmrgpuExt_getProfile(self.plan, _ptr(cnt), _ptr(ms)), "tfqmrgpuExt_getProfile")
+        return {k: (int(cnt[i]), float(ms[i])) for i, k in enumerate(self.PROFILE_CLASSES)}
 
     def close(self):
         if self.plan:

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <algorithm>
 #include <new>
+#include <vector>
 #include <dlfcn.h>
 
 #include "tfq_device.hpp"
@@ -160,10 +161,16 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
     bool const multi = (h.comm != nullptr) || (h.reduceFn != nullptr);
 
     constexpr int DEPTH = 4;
+    constexpr int NK = TFQMRGPU_PROFILE_CLASSES;
     Ctl* ring = nullptr;
     TFQ_HIP(hipHostMalloc((void**)&ring, DEPTH * sizeof(Ctl), hipHostMallocDefault), TFQMRGPU_STATUS_ALLOCATION_FAILED)
     hipEvent_t ev[DEPTH];
     for (auto& e : ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    // profiling: NK+1 timing events per in-flight iteration, event k sits in front of kernel class k
+    bool const prof = p.profiling;
+    std::vector<hipEvent_t> pev(prof ? DEPTH * (NK + 1) : 0);
+    for (auto& e : pev) (void)hipEventCreate(&e);
+    for (int k = 0; k < NK; ++k) { p.profLaunches[k] = 0; p.profMs[k] = 0; }
 
     p.boundHistory.clear();
     p.iterations_needed = maxIt; p.flops_performed = 0;
@@ -171,21 +178,24 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
 
     tfqmrgpuStatus_t fail = TFQMRGPU_STATUS_SUCCESS;
     auto enqueue = [&](int slot) {
-        vec_launch(VEC_DEC35, d, 0, 0, s);
-        vec_launch(VEC_XPAY_V6, d, 0, 0, s);
-        spmm_launch(EPI_XPAY_DOT, d, s);
-        vec_launch(VEC_DEC34, d, 0, 0, s);
-        vec_launch(VEC_V7_V5, d, 0, 0, s);
-        vec_launch(VEC_DECT_C67, d, 0, 0, s);
-        vec_launch(VEC_X_V6_V7, d, 0, 0, s);
-        spmm_launch(EPI_AXPY_NRM_DOT, d, s);
-        vec_launch(VEC_DECT_FIN, d, 0, 0, s);
-        vec_launch(VEC_X, d, 0, 0, s);
+        auto mark = [&](int k) { if (prof) (void)hipEventRecord(pev[slot * (NK + 1) + k], s); };
+        mark(TFQMRGPU_PROF_DEC35);            vec_launch(VEC_DEC35, d, 0, 0, s);
+        mark(TFQMRGPU_PROF_XPAY_V6);          vec_launch(VEC_XPAY_V6, d, 0, 0, s);
+        mark(TFQMRGPU_PROF_SPMM_V4_DOT);      spmm_launch(EPI_XPAY_DOT, d, s);
+        mark(TFQMRGPU_PROF_DEC34);            vec_launch(VEC_DEC34, d, 0, 0, s);
+        mark(TFQMRGPU_PROF_V7_V5_NRM);        vec_launch(VEC_V7_V5, d, 0, 0, s);
+        mark(TFQMRGPU_PROF_DECT_C67);         vec_launch(VEC_DECT_C67, d, 0, 0, s);
+        mark(TFQMRGPU_PROF_X_V6_V7);          vec_launch(VEC_X_V6_V7, d, 0, 0, s);
+        mark(TFQMRGPU_PROF_SPMM_V5_NRM_DOT);  spmm_launch(EPI_AXPY_NRM_DOT, d, s);
+        mark(TFQMRGPU_PROF_DECT_FINAL);       vec_launch(VEC_DECT_FIN, d, 0, 0, s);
+        mark(TFQMRGPU_PROF_X);                vec_launch(VEC_X, d, 0, 0, s);
+        mark(TFQMRGPU_PROF_DECIDE);
         if (multi) {
             launch_decide(d, 1, s);
             auto const st = reduce_over_ranks(h, d, 0, s); if (st) fail = st;
             launch_decide(d, 2, s);
         } else launch_decide(d, 0, s);
+        mark(TFQMRGPU_PROF_PROBE);
         spmm_launch(EPI_RESIDUAL, d, s);
         vec_launch(VEC_PROBE_COL, d, 0, 0, s);
         if (multi) {
@@ -193,6 +203,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
             auto const st = reduce_over_ranks(h, d, 2, s); if (st) fail = st;
             launch_probe_decide(d, 2, s);
         } else launch_probe_decide(d, 0, s);
+        mark(NK);
         (void)hipMemcpyAsync(&ring[slot], d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s);
         (void)hipEventRecord(ev[slot], s);
     };
@@ -202,16 +213,26 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
     int enq = 0, seen = 0;
     while (enq < std::min(DEPTH, maxIt)) { enqueue(enq % DEPTH); ++enq; }
     while (seen < enq && !fail) {
-        if (hipSuccess != hipEventSynchronize(ev[seen % DEPTH])) { fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED); break; }
-        last = ring[seen % DEPTH];
+        int const slot = seen % DEPTH;
+        if (hipSuccess != hipEventSynchronize(ev[slot])) { fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED); break; }
+        int const nprobes_before = last.nprobes;
+        last = ring[slot];
         ++seen;
         p.boundHistory.push_back(last.max_bound2);
+        if (prof) for (int k = 0; k < NK; ++k) {
+            if (TFQMRGPU_PROF_PROBE == k && last.nprobes == nprobes_before) continue; // gated off: empty launches
+            float ms = 0;
+            if (hipSuccess == hipEventElapsedTime(&ms, pev[slot * (NK + 1) + k], pev[slot * (NK + 1) + k + 1])) {
+                p.profMs[k] += ms; p.profLaunches[k] += 1;
+            }
+        }
         if (last.state != 0) break;
         if (enq < maxIt) { enqueue(enq % DEPTH); ++enq; }
     }
     (void)hipStreamSynchronize(s);
     if (hipSuccess != hipGetLastError() && !fail) fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
     for (auto& e : ev) (void)hipEventDestroy(e);
+    for (auto& e : pev) (void)hipEventDestroy(e);
     (void)hipHostFree(ring);
     if (fail) return fail;
 
@@ -571,6 +592,20 @@ int32_t tfqmrgpuExt_getBoundHistory(tfqmrgpuBsrsvPlan_t plan, double* bound2, in
     auto const n = int32_t(p->boundHistory.size());
     for (int32_t i = 0; i < std::min(n, capacity); ++i) if (bound2) bound2[i] = p->boundHistory[i];
     return n;
+}
+
+tfqmrgpuStatus_t tfqmrgpuExt_setProfiling(tfqmrgpuBsrsvPlan_t plan, int on) {
+    auto p = asPlan(plan);
+    if (!p) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    p->profiling = (0 != on);
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+tfqmrgpuStatus_t tfqmrgpuExt_getProfile(tfqmrgpuBsrsvPlan_t plan, int64_t* launches, double* milliseconds) {
+    auto p = asPlan(plan);
+    if (!p || !launches || !milliseconds) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    for (int k = 0; k < TFQMRGPU_PROFILE_CLASSES; ++k) { launches[k] = p->profLaunches[k]; milliseconds[k] = p->profMs[k]; }
+    return TFQMRGPU_STATUS_SUCCESS;
 }
 
 tfqmrgpuStatus_t tfqmrgpuExt_setShadowMode(tfqmrgpuBsrsvPlan_t plan, int mode) {

@@ -89,6 +89,9 @@ struct Plan {
     double residuum_reached = 0, flops_performed = -1, flops_performed_all = 0;
     int iterations_needed = -1;
     std::vector<double> boundHistory;
+    bool profiling = false;
+    int64_t profLaunches[16] = {};
+    double profMs[16] = {};
 
     size_t nPairs() const { return pairs.size() / 2; }
 };
