@@ -66,10 +66,9 @@ def kernel_model(pr, prec, nPairs, nA_ref):
     return {
         "xpay_v6": (3 * S, 8.0 * el),
         "spmm_v4_dot": (5 * S + S3 + A + idx, fm + 24.0 * el),
-        "v7_v5_nrm": (6 * S, 20.0 * el),
-        "x_v6_v7": (7 * S, 24.0 * el),
+        "v5_nrm": (3 * S, 12.0 * el),
+        "x_v6_v7": (7 * S, 40.0 * el),
         "spmm_v5_nrm_dot": (4 * S + S3 + A + idx, fm + 20.0 * el),
-        "x": (3 * S, 8.0 * el),
         "multiply": (2 * S + A + idx, fm),
     }
 
@@ -219,7 +218,7 @@ def main():
                       algorithmic_bytes=int(model["multiply"][0]), algorithmic_flops=float(model["multiply"][1]))
 
             S = pr.nnzbX * 2 * pr.LM * pr.LN * (8 if prec == "z" else 4)
-            it_bytes = sum(model[k][0] for k in ("xpay_v6", "spmm_v4_dot", "v7_v5_nrm", "x_v6_v7", "spmm_v5_nrm_dot", "x"))
+            it_bytes = sum(model[k][0] for k in ("xpay_v6", "spmm_v4_dot", "v5_nrm", "x_v6_v7", "spmm_v5_nrm_dot"))
             it_ms = sum(v["total_ms"] for k, v in per_kernel.items() if k != "probe") / max(1, iters)
             out = {
                 "metric": "tfQMR solve throughput to 1e-9 residual (reference flop count / solve time); iterations/s and BSR multiply GB/s + TFLOP/s in extra keys",

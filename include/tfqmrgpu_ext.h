@@ -47,8 +47,8 @@ int32_t tfqmrgpuExt_getBoundHistory(tfqmrgpuBsrsvPlan_t plan, double *bound2, in
  * the number of launches that did work and their summed duration in milliseconds. */
 enum {
     TFQMRGPU_PROF_DEC35 = 0, TFQMRGPU_PROF_XPAY_V6, TFQMRGPU_PROF_SPMM_V4_DOT, TFQMRGPU_PROF_DEC34,
-    TFQMRGPU_PROF_V7_V5_NRM, TFQMRGPU_PROF_DECT_C67, TFQMRGPU_PROF_X_V6_V7, TFQMRGPU_PROF_SPMM_V5_NRM_DOT,
-    TFQMRGPU_PROF_DECT_FINAL, TFQMRGPU_PROF_X, TFQMRGPU_PROF_DECIDE, TFQMRGPU_PROF_PROBE,
+    TFQMRGPU_PROF_V5_NRM, TFQMRGPU_PROF_DECT_C67, TFQMRGPU_PROF_X_V6_V7, TFQMRGPU_PROF_SPMM_V5_NRM_DOT,
+    TFQMRGPU_PROF_DECT_FINAL, TFQMRGPU_PROF_DECIDE, TFQMRGPU_PROF_PROBE,
     TFQMRGPU_PROFILE_CLASSES
 };
 tfqmrgpuStatus_t tfqmrgpuExt_setProfiling(tfqmrgpuBsrsvPlan_t plan, int on);

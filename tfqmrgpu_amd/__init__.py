@@ -271,8 +271,8 @@ class Solver:
             lib.tfqmrgpuExt_getBoundHistory(self.plan, _ptr(h), n)
         return h
 
-    PROFILE_CLASSES = ["dec35", "xpay_v6", "spmm_v4_dot", "dec34", "v7_v5_nrm", "decT_c67", "x_v6_v7",
-                       "spmm_v5_nrm_dot", "decT_final", "x", "decide", "probe"]
+    PROFILE_CLASSES = ["dec35", "xpay_v6", "spmm_v4_dot", "dec34", "v5_nrm", "decT_c67", "x_v6_v7",
+                       "spmm_v5_nrm_dot", "decT_final", "decide", "probe"]
 
     def set_profiling(self, on=True):
         _check(lib.tfqmrgpuExt_setProfiling(self.plan, int(on)), "tfqmrgpuExt_setProfiling")

@@ -29,12 +29,13 @@ DevPlan resolve(Plan const& p) {
     d.x = at(p.wX); d.v4 = at(p.wV4); d.v5 = at(p.wV5); d.v6 = at(p.wV6); d.v7 = at(p.wV7);
     d.v8 = at(p.wV8); d.v9 = at(p.wV9); d.B = at(p.wB); d.A = at(p.wA); d.v3 = (float*)at(p.wV3);
     d.rho = at(p.wRho); d.alfa = at(p.wAlfa); d.beta = at(p.wBeta); d.c67 = at(p.wC67); d.eta = at(p.wEta);
+    d.c67a = at(p.wC67a); d.eta2 = at(p.wEta2);
     d.z = (double*)at(p.wZ); d.d = (double*)at(p.wD); d.tau = (double*)at(p.wTau); d.var = (double*)at(p.wVar);
     d.invBn2 = (double*)at(p.wInvBn2); d.status = (int8_t*)at(p.wStatus); d.ctl = (Ctl*)at(p.wCtl);
     d.pz = (double*)at(p.wPz); d.pd = (double*)at(p.wPd); d.colrec = (double*)at(p.wColRec);
     d.chunkFirst = (uint32_t*)at(p.wChunkFirst); d.chunkCol = (uint32_t*)at(p.wChunkCol);
     d.colChunkPtr = (uint32_t*)at(p.wColChunkPtr); d.colStart = (uint32_t*)at(p.wColStart);
-    d.bOfX = (uint32_t*)at(p.wBofX); d.starts = (uint32_t*)at(p.wStarts); d.pairs = (uint32_t*)at(p.wPairs);
+    d.order = (uint32_t*)at(p.wOrder); d.bOfX = (uint32_t*)at(p.wBofX); d.starts = (uint32_t*)at(p.wStarts); d.pairs = (uint32_t*)at(p.wPairs);
     d.subset = (uint32_t*)at(p.wSubset); d.bColPtr = (uint32_t*)at(p.wBColPtr); d.bList = (uint32_t*)at(p.wBList);
     d.u2i = (uint32_t*)at(p.wU2I); d.rowI = (uint32_t*)at(p.wRowI); d.origCol = (int32_t*)at(p.wOrigCol);
     return d;
@@ -147,8 +148,8 @@ static tfqmrgpuStatus_t reduce_over_ranks(Handle& h, DevPlan const& d, int off, 
 
 // ---- the tfQMR driver -----------------------------------------------------------------------------
 // Algorithm = reference tfqmrgpu::solve (tfqmrgpu_core.hxx:179-306), restructured:
-//   dec35 | v6 | SpMM+v4+dot | dec34 | v7,v5,nrm | decT | x,v6,v7 | SpMM+v5+nrm+dot | decT | x | decide
-//   [ | SpMM residual | column records | decide ]   <- only does work when the bound asks for a probe
+//   dec35 | v6 | SpMM+v4+dot | dec34 | v5,nrm | decT | x,v7,v6,v7 | SpMM+v5+nrm+dot | decT | decide
+//   [ | x | SpMM residual | column records | decide ]   <- only does work when the bound asks for a probe
 // The host never waits for the iteration it has just enqueued: it keeps DEPTH iterations in flight
 // and reads the control block of iteration `it` (copied to pinned memory behind it) before it
 // enqueues iteration it+DEPTH.  Iterations enqueued after the solve has stopped cost a few empty
@@ -183,12 +184,11 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         mark(TFQMRGPU_PROF_XPAY_V6);          vec_launch(VEC_XPAY_V6, d, 0, 0, s);
         mark(TFQMRGPU_PROF_SPMM_V4_DOT);      spmm_launch(EPI_XPAY_DOT, d, s);
         mark(TFQMRGPU_PROF_DEC34);            vec_launch(VEC_DEC34, d, 0, 0, s);
-        mark(TFQMRGPU_PROF_V7_V5_NRM);        vec_launch(VEC_V7_V5, d, 0, 0, s);
+        mark(TFQMRGPU_PROF_V5_NRM);           vec_launch(VEC_V5_NRM, d, 0, 0, s);
         mark(TFQMRGPU_PROF_DECT_C67);         vec_launch(VEC_DECT_C67, d, 0, 0, s);
         mark(TFQMRGPU_PROF_X_V6_V7);          vec_launch(VEC_X_V6_V7, d, 0, 0, s);
         mark(TFQMRGPU_PROF_SPMM_V5_NRM_DOT);  spmm_launch(EPI_AXPY_NRM_DOT, d, s);
         mark(TFQMRGPU_PROF_DECT_FINAL);       vec_launch(VEC_DECT_FIN, d, 0, 0, s);
-        mark(TFQMRGPU_PROF_X);                vec_launch(VEC_X, d, 0, 0, s);
         mark(TFQMRGPU_PROF_DECIDE);
         if (multi) {
             launch_decide(d, 1, s);
@@ -196,6 +196,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
             launch_decide(d, 2, s);
         } else launch_decide(d, 0, s);
         mark(TFQMRGPU_PROF_PROBE);
+        vec_launch(VEC_X_FLUSH, d, 0, 0, s);
         spmm_launch(EPI_RESIDUAL, d, s);
         vec_launch(VEC_PROBE_COL, d, 0, 0, s);
         if (multi) {
@@ -390,6 +391,7 @@ tfqmrgpuStatus_t tfqmrgpu_bsrsv_setBuffer(tfqmrgpuHandle_t handle, tfqmrgpuBsrsv
     for (auto& o : orig) o -= p->indexOffset;
     if ((st = up(p->wChunkFirst, c.first.data(), c.first.size() * 4))) return st;
     if ((st = up(p->wChunkCol, c.col.data(), c.col.size() * 4))) return st;
+    if ((st = up(p->wOrder, c.order.data(), c.order.size() * 4))) return st;
     if ((st = up(p->wColChunkPtr, c.colPtr.data(), c.colPtr.size() * 4))) return st;
     if ((st = up(p->wColStart, p->colStart.data(), p->colStart.size() * 4))) return st;
     if ((st = up(p->wOrigCol, orig.data(), orig.size() * 4))) return st;

@@ -24,7 +24,8 @@ struct Ctl {
     int32_t probe;             // the true residual has to be computed now
     int32_t iterations_needed;
     int32_t nprobes;
-    int32_t pad[2];
+    int32_t xpend;             // x += eta2*v7 of the last iteration has not been applied yet
+    int32_t pad[1];
 };
 static_assert(sizeof(Ctl) == 96, "Ctl is copied as 96 bytes");
 
@@ -36,12 +37,13 @@ struct DevPlan {
     void *x, *v4, *v5, *v6, *v7, *v8, *v9, *B, *A;
     float* v3;
     void *rho, *alfa, *beta, *c67, *eta;       // [nCols][2][LN] real
+    void *c67a, *eta2;                         // dec34's c67 / the eta of the second half step
     double *z, *d, *tau, *var, *invBn2;        // [nCols][2|1][LN]
     int8_t* status;                            // [nCols][LN]
     Ctl* ctl;
     double *pz, *pd;                           // [nChunks][2|1][LN]
     double* colrec;                            // [nCols][2]
-    uint32_t const *chunkFirst, *chunkCol, *colChunkPtr, *colStart, *bOfX;
+    uint32_t const *chunkFirst, *chunkCol, *colChunkPtr, *colStart, *bOfX, *order;
     uint32_t const *starts, *pairs, *subset, *bColPtr, *bList, *u2i, *rowI;
     int32_t const* origCol;
 };

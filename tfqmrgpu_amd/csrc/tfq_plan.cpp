@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <numeric>
 
@@ -241,6 +242,36 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
         }
         c.colPtr[p.nCols] = uint32_t(c.col.size());
         c.first.push_back(p.nnzbX);
+
+        // Launch order of the multiply.  Work groups are dealt round-robin to the 8 XCDs (observed,
+        // used for speed only), each XCD has its own 4 MiB L2.  Chunks are sorted by
+        // (group of G block columns, band of block rows, column, row) and the sorted list is cut
+        // into 8 contiguous parts, one per XCD: inside an XCD consecutive work groups then walk down a
+        // band of rows for G columns, so X blocks shared by neighbouring rows and A blocks shared by
+        // the G columns are re-read from that L2 instead of the fabric.
+        uint32_t const n = uint32_t(c.col.size());
+        auto envu = [](char const* name, uint32_t dflt) { auto v = std::getenv(name); return v ? uint32_t(std::atoi(v)) : dflt; };
+        uint32_t const mode = envu("TFQMRGPU_ORDER", 1), G = std::max(1u, envu("TFQMRGPU_ORDER_G", 8)), band = std::max(1u, envu("TFQMRGPU_ORDER_BAND", 64));
+        std::vector<uint32_t> sorted(n);
+        std::iota(sorted.begin(), sorted.end(), 0u);
+        c.order = sorted;
+        if (mode && n >= 64) {
+            std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b) {
+                uint32_t const ga = c.col[a] / G, gb = c.col[b] / G;
+                if (ga != gb) return ga < gb;
+                uint32_t const ba = p.rowI[c.first[a]] / band, bb = p.rowI[c.first[b]] / band;
+                if (ba != bb) return ba < bb;
+                if (c.col[a] != c.col[b]) return c.col[a] < c.col[b];
+                return a < b;
+            });
+            uint32_t const q = n / 8, r = n % 8;
+            std::vector<uint32_t> begin(9, 0);
+            for (uint32_t x = 0; x < 8; ++x) begin[x + 1] = begin[x] + q + (x < r ? 1 : 0);
+            uint32_t w = 0;
+            for (uint32_t i = 0; i <= q; ++i)
+                for (uint32_t x = 0; x < 8; ++x)
+                    if (begin[x] + i < begin[x + 1]) c.order[w++] = sorted[begin[x] + i];
+        }
     }
     size_t const nChunks = p.chunks.col.size();
 
@@ -253,6 +284,7 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     take(p.wB, size_t(p.nnzbB) * blockElems * p.realBytes);
     size_t const cs = size_t(p.nCols) * 2 * LN * p.realBytes;
     take(p.wRho, cs); take(p.wAlfa, cs); take(p.wBeta, cs); take(p.wC67, cs); take(p.wEta, cs);
+    take(p.wC67a, cs); take(p.wEta2, cs);
     take(p.wZ,   size_t(p.nCols) * 2 * LN * sizeof(double));
     take(p.wD,   size_t(p.nCols) * LN * sizeof(double));
     take(p.wTau, size_t(p.nCols) * LN * sizeof(double));
@@ -265,6 +297,7 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     take(p.wColRec, size_t(p.nCols) * 2 * sizeof(double)); // per-column stopping-test record
     take(p.wChunkFirst, (nChunks + 1) * sizeof(uint32_t));
     take(p.wChunkCol, nChunks * sizeof(uint32_t));
+    take(p.wOrder, nChunks * sizeof(uint32_t));
     take(p.wColChunkPtr, (size_t(p.nCols) + 1) * sizeof(uint32_t));
     take(p.wColStart, (size_t(p.nCols) + 1) * sizeof(uint32_t));
     take(p.wOrigCol, size_t(p.nCols) * sizeof(int32_t));

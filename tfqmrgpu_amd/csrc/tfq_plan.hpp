@@ -26,6 +26,7 @@ struct ChunkTable {
     std::vector<uint32_t> first;   // [nChunks+1] first internal block of each chunk
     std::vector<uint32_t> col;     // [nChunks]   compressed block column
     std::vector<uint32_t> colPtr;  // [nCols+1]   first chunk of each column
+    std::vector<uint32_t> order;   // [nChunks]   launch order of the multiply (XCD aware)
 };
 
 struct Handle {
@@ -72,13 +73,13 @@ struct Plan {
 
     // windows into the user's device buffer
     Window wX, wV4, wV5, wV6, wV7, wV8, wV9, wV3, wB, wA;
-    Window wRho, wAlfa, wBeta, wC67, wEta;     // [nCols][2][LN] real
+    Window wRho, wAlfa, wBeta, wC67, wEta, wC67a, wEta2; // [nCols][2][LN] real
     Window wZ, wD, wTau, wVar, wInvBn2;        // double scalars per right-hand side
     Window wStatus;                            // int8 [nCols][LN]
     Window wCtl;                               // device control block (see tfq_solver)
     Window wPz, wPd;                           // per-chunk partial sums (double)
     Window wColRec;                            // per-column stopping-test record [nCols][2] double
-    Window wChunkFirst, wChunkCol, wColChunkPtr, wColStart, wOrigCol, wBofX;
+    Window wChunkFirst, wChunkCol, wColChunkPtr, wColStart, wOrigCol, wBofX, wOrder;
     Window wStarts, wPairs, wSubset, wBColPtr, wBList, wU2I, wRowI;
 
     char* buffer = nullptr;            // device buffer registered by setBuffer

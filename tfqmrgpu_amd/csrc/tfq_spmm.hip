@@ -30,6 +30,7 @@ struct SpmmArgs {
     uint32_t nY;                       // number of Y blocks (plain mode)
     uint32_t const* chunkFirst;        // nullptr: plain mode, chunk b = blocks [b*CH, (b+1)*CH)
     uint32_t const* chunkCol;
+    uint32_t const* order;             // launch order: work group b processes chunk order[b] (nullptr: b)
     uint32_t CH;
     Ctl const* ctl; int gate;          // 0: always run, 1: skip when the solve has stopped, 2: only when probing
     void* e0; void const* e1; void const* sc; float const* v3;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void k_spmm_direct(SpmmArgs a) {
     int const g = (P >= 256) ? 0 : t / P;
     int const e0 = (P >= 256) ? t : t % P;
     bool const active = (g < GRP);
-    uint32_t const chunk = blockIdx.x;
+    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;
     uint32_t first, last, col = 0;
     if (a.chunkFirst) { first = a.chunkFirst[chunk]; last = a.chunkFirst[chunk + 1]; col = a.chunkCol[chunk]; }
     else { first = chunk * a.CH; last = min(first + a.CH, a.nY); }
@@ -186,17 +187,53 @@ template <> struct Acc<float> {
     __device__ static inline int row(int lane, int r) { return 4 * (lane >> 4) + r; }
 };
 
+// operands of one "slice" = KSL consecutive MFMA k-steps (4 k each) of one block product
+template <typename R, int NT, int KSL>
+struct Slice {
+    R ar[KSL], ai[KSL], xr[KSL][NT], xi[KSL][NT];
+    template <int LM, int LN>
+    __device__ inline void load(R const* __restrict__ Ab, R const* __restrict__ Xb, int k0, int lr) {
+        constexpr int P = LM * LN;
+#pragma unroll
+        for (int s = 0; s < KSL; ++s) {
+            int const k = k0 + 4 * s + lr;
+            ar[s] = Ab[k * LM]; ai[s] = Ab[LM * LM + k * LM];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { xr[s][nt] = Xb[k * LN + nt * 16]; xi[s][nt] = Xb[P + k * LN + nt * 16]; }
+        }
+    }
+    template <typename T4>
+    __device__ inline void mma(T4 (&cre)[NT], T4 (&cim)[NT]) const {
+#pragma unroll
+        for (int s = 0; s < KSL; ++s) {
+            R const nai = -ai[s];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                cre[nt] = Acc<R>::mma(ar[s], xr[s][nt], cre[nt]);
+                cim[nt] = Acc<R>::mma(ar[s], xi[s][nt], cim[nt]);
+                cre[nt] = Acc<R>::mma(nai, xi[s][nt], cre[nt]);
+                cim[nt] = Acc<R>::mma(ai[s], xr[s][nt], cim[nt]);
+            }
+        }
+    }
+};
+
 template <typename R, int LM, int LN, int EPI>
 __global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
     if (gate_closed(a)) return;
     static_assert(LM % 16 == 0 && LN % 16 == 0, "MFMA tiles are 16 x 16");
     constexpr int P = LM * LN, MT = LM / 16, NT = LN / 16;
+    constexpr int KSL = (NT >= 4) ? 2 : 4;           // k-steps per slice: bounds the registers of the prefetch
+    constexpr int SPP = LM / (4 * KSL);              // slices per block product
     constexpr int NPL = EpiPlanes<EPI>::N;
     using T4 = typename Acc<R>::T;
     int const lane = threadIdx.x & 63;
     int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int const lr = lane >> 4, lc = lane & 15;
-    uint32_t const chunk = blockIdx.x;
+    // work groups that are dispatched to the same XCD (blockIdx % 8, observed round-robin) get
+    // neighbouring chunks (a.order), so that the X blocks shared by neighbouring block rows and the
+    // A blocks shared by neighbouring block columns are served by that XCD's L2
+    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;
     uint32_t first, last, col = 0;
     if (a.chunkFirst) { first = a.chunkFirst[chunk]; last = a.chunkFirst[chunk + 1]; col = a.chunkCol[chunk]; }
     else { first = chunk * a.CH; last = min(first + a.CH, a.nY); }
@@ -220,25 +257,29 @@ __global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
         T4 cre[NT], cim[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) { cre[nt] = T4{0, 0, 0, 0}; cim[nt] = T4{0, 0, 0, 0}; }
-        uint32_t const q0 = a.starts[y], q1 = a.starts[y + 1];
-        for (uint32_t q = q0; q < q1; ++q) {
-            R const* Ab = (R const*)a.A + size_t(a.pairs[2 * size_t(q)]) * 2 * LM * LM + i0 + lc;
-            R const* Xb = (R const*)a.X + size_t(a.pairs[2 * size_t(q) + 1]) * 2 * P + lc;
-#pragma unroll 4
-            for (int k0 = 0; k0 < LM; k0 += 4) {
-                int const k = k0 + lr;
-                R const ar = Ab[k * LM], ai = Ab[LM * LM + k * LM];
-                R const nai = -ai;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    R const xr = Xb[k * LN + nt * 16], xi = Xb[P + k * LN + nt * 16];
-                    cre[nt] = Acc<R>::mma(ar, xr, cre[nt]);
-                    cim[nt] = Acc<R>::mma(ar, xi, cim[nt]);
-                    cre[nt] = Acc<R>::mma(nai, xi, cre[nt]);
-                    cim[nt] = Acc<R>::mma(ai, xr, cim[nt]);
-                }
-            }
+        uint32_t const q0 = a.starts[y];
+        uint32_t const nT = (a.starts[y + 1] - q0) * SPP;   // slices of this strip
+        R const* const A0 = (R const*)a.A + i0 + lc;
+        R const* const X0 = (R const*)a.X + lc;
+        auto fetch = [&](Slice<R, NT, KSL>& o, uint32_t t) {
+            uint32_t const q = q0 + t / SPP;
+            int const k0 = int(t % SPP) * (4 * KSL);
+            o.template load<LM, LN>(A0 + size_t(a.pairs[2 * size_t(q)]) * 2 * LM * LM,
+                                    X0 + size_t(a.pairs[2 * size_t(q) + 1]) * 2 * P, k0, lr);
+        };
+        // software pipeline, two register sets: the loads of slice t+1 are in flight while the MFMAs of
+        // slice t issue (one wave alone keeps the matrix pipe busy; co-resident waves cover the rest)
+        Slice<R, NT, KSL> o0, o1;
+        if (nT > 0) fetch(o0, 0);
+        uint32_t t = 0;
+        for (; t + 2 <= nT; t += 2) {
+            fetch(o1, t + 1);
+            o0.mma(cre, cim);
+            if (t + 2 < nT) fetch(o0, t + 2);
+            o1.mma(cre, cim);
         }
+        if (t < nT) o0.mma(cre, cim);
+
         uint32_t bq = 0xffffffffu;
         if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
 #pragma unroll
@@ -308,7 +349,7 @@ static bool spmm_dispatch(bool dbl, int lm, int ln, int epi, SpmmArgs const& a, 
 void spmm_launch(int epi, DevPlan const& d, hipStream_t s) {
     SpmmArgs a{};
     a.A = d.A; a.starts = d.starts; a.pairs = d.pairs; a.nY = d.nnzbX;
-    a.chunkFirst = d.chunkFirst; a.chunkCol = d.chunkCol; a.CH = 0;
+    a.chunkFirst = d.chunkFirst; a.chunkCol = d.chunkCol; a.order = d.order; a.CH = 0;
     a.ctl = d.ctl; a.v3 = d.v3; a.B = d.B; a.bOfX = d.bOfX; a.pz = d.pz; a.pd = d.pd;
     switch (epi) {
     case EPI_XPAY_DOT:     a.X = d.v6; a.Y = d.v9; a.e0 = d.v4; a.e1 = d.v8; a.sc = d.beta; a.gate = 1; break;

@@ -9,7 +9,7 @@
 //    registers until one [LN] record per chunk is written (no memset + tree of launches);
 //  * every lane moves 16 bytes per access (2 doubles / 4 floats) along the contiguous RHS index;
 //  * updates that the reference launches one by one are fused (each vector is read/written once
-//    between two scalar barriers);
+//    between two scalar barriers), the second x update of an iteration rides on the next iteration;
 //  * reductions are deterministic: fixed shuffle-free LDS order inside a work group, fixed chunk
 //    order per column in the decision kernels.
 #include "tfq_device.hpp"
@@ -158,23 +158,21 @@ __global__ __launch_bounds__(256) void k_xpay_v6(DevPlan d) {
     }
 }
 
-// ---- KC: v7 := v6 + c67 v7 ; v5 := alfa v9 + v5 ; pd <- |v5|^2 ----------------------------------------
+// ---- KC: v5 := alfa v9 + v5 ; pd <- |v5|^2 ---------------------------------------------------------
+// (the v7 update that the reference does here, tfqmrgpu_core.hxx:207, needs v6 and v7 again in KD and
+// is done there: same arithmetic, one read of v6 and one read+write of v7 less)
 template <typename R, int LM, int LN>
-__global__ __launch_bounds__(256) void k_v7_v5_nrm(DevPlan d) {
+__global__ __launch_bounds__(256) void k_v5_nrm(DevPlan d) {
     using G = Geo<R, LM, LN>;
     __shared__ double s[256 * G::VEC];
     TFQ_CHUNK_PROLOGUE(G)
-    R const* v6 = (R const*)d.v6; R* v7 = (R*)d.v7; R* v5 = (R*)d.v5; R const* v9 = (R const*)d.v9;
+    R* v5 = (R*)d.v5; R const* v9 = (R const*)d.v9;
     double acc[1][G::VEC] = {};
     if (t < G::T) {
-        Scal<R, LN, G::VEC> c67, alfa; c67.load((R const*)d.c67, col, t); alfa.load((R const*)d.alfa, col, t);
+        Scal<R, LN, G::VEC> alfa; alfa.load((R const*)d.alfa, col, t);
         for (uint32_t w = t; w < nItems; w += G::T) {
             TFQ_ITEM_OFFSETS(G)
             R ar[G::VEC], ai[G::VEC], br[G::VEC], bi[G::VEC];
-            ldv(ar, v6 + re); ldv(ai, v6 + im); ldv(br, v7 + re); ldv(bi, v7 + im);
-#pragma unroll
-            for (int v = 0; v < G::VEC; ++v) xpay(br[v], bi[v], ar[v], ai[v], c67.re[v], c67.im[v]);
-            stv(v7 + re, br); stv(v7 + im, bi);
             ldv(ar, v9 + re); ldv(ai, v9 + im); ldv(br, v5 + re); ldv(bi, v5 + im);
 #pragma unroll
             for (int v = 0; v < G::VEC; ++v) {
@@ -188,15 +186,21 @@ __global__ __launch_bounds__(256) void k_v7_v5_nrm(DevPlan d) {
     chunk_reduce<LN, G::VEC, G::T, 1>(acc, s, d.pd + size_t(chunk) * LN, t);
 }
 
-// ---- KD: x := eta v7 + x ; v6 := alfa v4 + v6 ; v7 := v6 + c67 v7 ------------------------------------
+// ---- KD: [x += eta2 v7 (left over from the previous iteration)] ; v7 := v6 + c67a v7 ; x += eta v7 ;
+//          v6 += alfa v4 ; v7 := v6 + c67 v7      (tfqmrgpu_core.hxx:233 | 207, 216, 218, 220)
+// c67a is the coefficient of dec34, c67 the one decT has produced since; eta2 is the eta of the second
+// half step of the previous iteration, whose x update is applied here unless a residual probe needed x
+// earlier (ctl->xpend == 0).
 template <typename R, int LM, int LN>
 __global__ __launch_bounds__(256) void k_x_v6_v7(DevPlan d) {
     using G = Geo<R, LM, LN>;
     TFQ_CHUNK_PROLOGUE(G)
     if (t >= G::T) return;
+    bool const pend = (d.ctl->xpend != 0);
     R* x = (R*)d.x; R* v6 = (R*)d.v6; R* v7 = (R*)d.v7; R const* v4 = (R const*)d.v4;
-    Scal<R, LN, G::VEC> eta, alfa, c67;
-    eta.load((R const*)d.eta, col, t); alfa.load((R const*)d.alfa, col, t); c67.load((R const*)d.c67, col, t);
+    Scal<R, LN, G::VEC> eta, eta2, alfa, c67, c67a;
+    eta.load((R const*)d.eta, col, t); eta2.load((R const*)d.eta2, col, t); alfa.load((R const*)d.alfa, col, t);
+    c67.load((R const*)d.c67, col, t); c67a.load((R const*)d.c67a, col, t);
     for (uint32_t w = t; w < nItems; w += G::T) {
         TFQ_ITEM_OFFSETS(G)
         R sr[G::VEC], si[G::VEC], xr[G::VEC], xi[G::VEC], ar[G::VEC], ai[G::VEC], br[G::VEC], bi[G::VEC];
@@ -204,22 +208,25 @@ __global__ __launch_bounds__(256) void k_x_v6_v7(DevPlan d) {
         ldv(ar, v4 + re); ldv(ai, v4 + im); ldv(br, v6 + re); ldv(bi, v6 + im);
 #pragma unroll
         for (int v = 0; v < G::VEC; ++v) {
-            axpy(xr[v], xi[v], sr[v], si[v], eta.re[v], eta.im[v]);       // x  += eta  v7
-            axpy(br[v], bi[v], ar[v], ai[v], alfa.re[v], alfa.im[v]);     // v6 += alfa v4
-            xpay(sr[v], si[v], br[v], bi[v], c67.re[v], c67.im[v]);       // v7  = v6 + c67 v7
+            if (pend) axpy(xr[v], xi[v], sr[v], si[v], eta2.re[v], eta2.im[v]);  // x  += eta2 v7   (previous iteration)
+            xpay(sr[v], si[v], br[v], bi[v], c67a.re[v], c67a.im[v]);           // v7  = v6 + c67a v7
+            axpy(xr[v], xi[v], sr[v], si[v], eta.re[v], eta.im[v]);             // x  += eta  v7
+            axpy(br[v], bi[v], ar[v], ai[v], alfa.re[v], alfa.im[v]);           // v6 += alfa v4
+            xpay(sr[v], si[v], br[v], bi[v], c67.re[v], c67.im[v]);             // v7  = v6 + c67 v7
         }
         stv(x + re, xr); stv(x + im, xi); stv(v6 + re, br); stv(v6 + im, bi); stv(v7 + re, sr); stv(v7 + im, si);
     }
 }
 
-// ---- KF: x := eta v7 + x ---------------------------------------------------------------------------
+// ---- KF: x := eta2 v7 + x, only when the true residual is about to be computed (tfqmrgpu_core.hxx:233) ---
 template <typename R, int LM, int LN>
-__global__ __launch_bounds__(256) void k_x(DevPlan d) {
+__global__ __launch_bounds__(256) void k_x_flush(DevPlan d) {
     using G = Geo<R, LM, LN>;
+    if (d.ctl->probe == 0 || d.ctl->xpend == 0) return;
     TFQ_CHUNK_PROLOGUE(G)
     if (t >= G::T) return;
     R* x = (R*)d.x; R const* v7 = (R const*)d.v7;
-    Scal<R, LN, G::VEC> eta; eta.load((R const*)d.eta, col, t);
+    Scal<R, LN, G::VEC> eta; eta.load((R const*)d.eta2, col, t);
     for (uint32_t w = t; w < nItems; w += G::T) {
         TFQ_ITEM_OFFSETS(G)
         R sr[G::VEC], si[G::VEC], xr[G::VEC], xi[G::VEC];
@@ -291,7 +298,8 @@ __global__ __launch_bounds__(256) void k_dec34(DevPlan d) {
     int const j = threadIdx.x;
     if (j >= LN) return;
     size_t const ir = (size_t(col) * 2 + 0) * LN + j, ii = ir + LN;
-    R const* rho = (R const*)d.rho; R const* eta = (R const*)d.eta; R* alf = (R*)d.alfa; R* c67 = (R*)d.c67;
+    // the latest eta is the one of the second half step of the previous iteration (eta2)
+    R const* rho = (R const*)d.rho; R const* eta = (R const*)d.eta2; R* alf = (R*)d.alfa; R* c67 = (R*)d.c67a;
     double const rr = double(rho[ir]), ri = double(rho[ii]);
     double const abs2rho = rr * rr + ri * ri, abs2z = z[0] * z[0] + z[1] * z[1];
     d.z[ir] = z[0]; d.z[ii] = z[1];
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(256) void k_decT(DevPlan d) {
     int const j = threadIdx.x;
     if (j < LN) {
         size_t const ir = (size_t(col) * 2 + 0) * LN + j, ii = ir + LN, i1 = size_t(col) * LN + j;
-        R const* alf = (R const*)d.alfa; R* eta = (R*)d.eta; R* c67 = (R*)d.c67;
+        R const* alf = (R const*)d.alfa; R* eta = (R*)(FINAL ? d.eta2 : d.eta); R* c67 = (R*)d.c67;
         double cosi = 0; R r67 = 1;
         double const Tau = d.tau[i1];
         int8_t st = d.status[i1];
@@ -416,6 +424,7 @@ __global__ __launch_bounds__(256) void k_decide(DevPlan d, int what, int phase) 
         int probe = (bound2 <= c->target_bound2) || (it >= c->maxIterations);
         if (c->red[1] == 0.) { c->state = 2; probe = 0; } // every right-hand side broke down
         c->probe = probe;
+        c->xpend = 1;   // x += eta2 v7 of this iteration is still outstanding
     } else {
         double max_res2 = 1.4e-76;
         if (c->red[2] > max_res2) max_res2 = c->red[2];
@@ -423,6 +432,7 @@ __global__ __launch_bounds__(256) void k_decide(DevPlan d, int what, int phase) 
         c->target_bound2 = (c->max_bound2 / max_res2) * c->tol2;
         c->nprobes += 1;
         c->probe = 0;
+        c->xpend = 0;   // k_x_flush has brought x up to date
         if (c->red[3] == 0.) { c->iterations_needed = c->iteration; c->state = 1; }
         else if (c->iteration >= c->maxIterations) c->state = 3;
     }
@@ -466,6 +476,7 @@ __global__ __launch_bounds__(256) void k_init_col(DevPlan d, double tol, int max
         ((R*)d.rho)[ir] = 1; ((R*)d.rho)[ii] = 0;
         ((R*)d.alfa)[ir] = 0; ((R*)d.alfa)[ii] = 0; ((R*)d.beta)[ir] = 0; ((R*)d.beta)[ii] = 0;
         ((R*)d.c67)[ir] = 0; ((R*)d.c67)[ii] = 0; ((R*)d.eta)[ir] = 0; ((R*)d.eta)[ii] = 0;
+        ((R*)d.c67a)[ir] = 0; ((R*)d.c67a)[ii] = 0; ((R*)d.eta2)[ir] = 0; ((R*)d.eta2)[ii] = 0;
     }
     if (0 == col && 0 == t) {
         Ctl* c = d.ctl;
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(256) void k_init_col(DevPlan d, double tol, int max
         c->red[0] = c->red[1] = c->red[2] = c->red[3] = 0;
         c->iteration = 0; c->maxIterations = maxIterations;
         c->state = (maxIterations > 0) ? 0 : 3;
-        c->probe = 0; c->iterations_needed = maxIterations; c->nprobes = 0;
+        c->probe = 0; c->iterations_needed = maxIterations; c->nprobes = 0; c->xpend = 0;
     }
 }
 
@@ -498,11 +509,11 @@ static void vec_run(int op, DevPlan const& d, double tol, int maxIt, hipStream_t
     case VEC_DEC35:    k_dec35<R, LN><<<cols, blk, 0, s>>>(d); break;
     case VEC_XPAY_V6:  k_xpay_v6<R, LM, LN><<<grid, blk, 0, s>>>(d); break;
     case VEC_DEC34:    k_dec34<R, LN><<<cols, blk, 0, s>>>(d); break;
-    case VEC_V7_V5:    k_v7_v5_nrm<R, LM, LN><<<grid, blk, 0, s>>>(d); break;
+    case VEC_V5_NRM:   k_v5_nrm<R, LM, LN><<<grid, blk, 0, s>>>(d); break;
     case VEC_DECT_C67: k_decT<R, LN, true, false><<<cols, blk, 0, s>>>(d); break;
     case VEC_X_V6_V7:  k_x_v6_v7<R, LM, LN><<<grid, blk, 0, s>>>(d); break;
     case VEC_DECT_FIN: k_decT<R, LN, false, true><<<cols, blk, 0, s>>>(d); break;
-    case VEC_X:        k_x<R, LM, LN><<<grid, blk, 0, s>>>(d); break;
+    case VEC_X_FLUSH:  k_x_flush<R, LM, LN><<<grid, blk, 0, s>>>(d); break;
     case VEC_PROBE_COL: k_probe_col<LN><<<cols, blk, 0, s>>>(d); break;
     }
 }

@@ -9,11 +9,11 @@ enum {
     VEC_DEC35,         // beta, rho from pz
     VEC_XPAY_V6,       // v6 := v5 + beta v6
     VEC_DEC34,         // alfa, c67 from pz
-    VEC_V7_V5,         // v7 := v6 + c67 v7 ; v5 += alfa v9 ; pd <- |v5|^2
+    VEC_V5_NRM,        // v5 += alfa v9 ; pd <- |v5|^2
     VEC_DECT_C67,      // tau, var, eta, c67 from pd
-    VEC_X_V6_V7,       // x += eta v7 ; v6 += alfa v4 ; v7 := v6 + c67 v7
+    VEC_X_V6_V7,       // [x += eta2 v7] ; v7 := v6 + c67a v7 ; x += eta v7 ; v6 += alfa v4 ; v7 := v6 + c67 v7
     VEC_DECT_FIN,      // tau, var, eta from pd + per-column stopping record
-    VEC_X,             // x += eta v7
+    VEC_X_FLUSH,       // x += eta2 v7, only in front of a residual probe
     VEC_PROBE_COL      // per-column residual record from pd
 };
 
