@@ -163,9 +163,13 @@ def main():
             flops += info["flops"]
             iters += info["iterations"]
             for k, (n, ms) in s.profile().items():
-                a = prof.setdefault(k, [0, 0.0])
+                a = prof.setdefault(k, [0, 0.0, 0, 0.0])
                 a[0] += n
                 a[1] += ms
+            for k, (n, ms) in s.profile(gated=True).items():
+                a = prof.setdefault(k, [0, 0.0, 0, 0.0])
+                a[2] += n
+                a[3] += ms
         barrier()
         elapsed = time.perf_counter() - t0
         s.set_profiling(False)
@@ -184,10 +188,14 @@ def main():
             nPairs = view["nPairs"]
             nA_ref = len(np.unique(view["pairs"][0::2]))
             model = kernel_model(pr, prec, nPairs, nA_ref)
-            per_kernel = {k: dict(launches=n, avg_ms=round(ms / n, 5), total_ms=round(ms, 3)) for k, (n, ms) in prof.items() if n}
+            # avg_ms: launches that did work; avg_ms_all_launches also counts the launches that were enqueued ahead
+            # of the stopping decision and returned at once (what a profiler's per-kernel average shows)
+            per_kernel = {k: dict(launches=n, avg_ms=round(ms / n, 5), total_ms=round(ms, 3), gated_off_launches=gn,
+                                  avg_ms_all_launches=round((ms + gms) / (n + gn), 5)) for k, (n, ms, gn, gms) in prof.items() if n}
             dom = max((k for k in per_kernel if k in model), key=lambda k: per_kernel[k]["total_ms"])
             rl = roof(model[dom][0], model[dom][1], per_kernel[dom]["avg_ms"], prec)
             rl.update(kernel=dom, avg_ms=per_kernel[dom]["avg_ms"], launches=per_kernel[dom]["launches"],
+                      gated_off_launches=per_kernel[dom]["gated_off_launches"], avg_ms_all_launches=per_kernel[dom]["avg_ms_all_launches"],
                       algorithmic_bytes=int(model[dom][0]), algorithmic_flops=float(model[dom][1]), traffic=None)
             tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tp):

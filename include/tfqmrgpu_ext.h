@@ -53,6 +53,9 @@ enum {
 };
 tfqmrgpuStatus_t tfqmrgpuExt_setProfiling(tfqmrgpuBsrsvPlan_t plan, int on);
 tfqmrgpuStatus_t tfqmrgpuExt_getProfile(tfqmrgpuBsrsvPlan_t plan, int64_t *launches, double *milliseconds);
+/* the launches that were enqueued ahead of the stopping decision and returned without doing work
+ * (a profiler counts them as calls of the same kernels) */
+tfqmrgpuStatus_t tfqmrgpuExt_getProfileGated(tfqmrgpuBsrsvPlan_t plan, int64_t *launches, double *milliseconds);
 
 /* ---- (2) shadow vector v3 -------------------------------------------------------------- */
 enum {

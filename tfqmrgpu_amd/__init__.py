@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = [  # include/tfqmrgpu.h
 ]
 EXT_SYMBOLS = [  # include/tfqmrgpu_ext.h
     "tfqmrgpuExt_planView", "tfqmrgpuExt_getBoundHistory", "tfqmrgpuExt_setProfiling", "tfqmrgpuExt_getProfile",
+    "tfqmrgpuExt_getProfileGated",
     "tfqmrgpuExt_setShadowMode",
     "tfqmrgpuExt_setShadowVector", "tfqmrgpuExt_multiply", "tfqmrgpuExt_shardColumns",
     "tfqmrgpuExt_freeShard", "tfqmrgpuExt_commUniqueId", "tfqmrgpuExt_commInit",
@@ -107,6 +108,7 @@ def load_library(path=LIB_PATH):
     lib.tfqmrgpuExt_getBoundHistory.argtypes = [P, P, C.c_int32]
     lib.tfqmrgpuExt_setProfiling.argtypes = [P, I]
     lib.tfqmrgpuExt_getProfile.argtypes = [P, P, P]
+    lib.tfqmrgpuExt_getProfileGated.argtypes = [P, P, P]
     lib.tfqmrgpuExt_setShadowMode.argtypes = [P, I]
     lib.tfqmrgpuExt_setShadowVector.argtypes = [P, P, P]
     lib.tfqmrgpuExt_multiply.argtypes = [P, C.c_char, I, I, C.c_uint32, P, P, P, P, P]
@@ -277,11 +279,12 @@ class Solver:
     def set_profiling(self, on=True):
         _check(lib.tfqmrgpuExt_setProfiling(self.plan, int(on)), "tfqmrgpuExt_setProfiling")
 
-    def profile(self):
-        """{kernel class: (launches, total ms)} of the last solve"""
+    def profile(self, gated=False):
+        """{kernel class: (launches, total ms)} of the last solve; gated=True: the launches that returned at once"""
         n = len(self.PROFILE_CLASSES)
         cnt, ms = np.zeros(n, np.int64), np.zeros(n, np.float64)
-        _check(lib.tfqmrgpuExt_getProfile(self.plan, _ptr(cnt), _ptr(ms)), "tfqmrgpuExt_getProfile")
+        fn = lib.tfqmrgpuExt_getProfileGated if gated else lib.tfqmrgpuExt_getProfile
+        _check(fn(self.plan, _ptr(cnt), _ptr(ms)), "tfqmrgpuExt_getProfile")
         return {k: (int(cnt[i]), float(ms[i])) for i, k in enumerate(self.PROFILE_CLASSES)}
 
     def close(self):

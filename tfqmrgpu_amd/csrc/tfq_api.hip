@@ -171,7 +171,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
     bool const prof = p.profiling;
     std::vector<hipEvent_t> pev(prof ? DEPTH * (NK + 1) : 0);
     for (auto& e : pev) (void)hipEventCreate(&e);
-    for (int k = 0; k < NK; ++k) { p.profLaunches[k] = 0; p.profMs[k] = 0; }
+    for (int k = 0; k < NK; ++k) { p.profLaunches[k] = 0; p.profMs[k] = 0; p.profGatedLaunches[k] = 0; p.profGatedMs[k] = 0; }
 
     p.boundHistory.clear();
     p.iterations_needed = maxIt; p.flops_performed = 0;
@@ -221,16 +221,27 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         ++seen;
         p.boundHistory.push_back(last.max_bound2);
         if (prof) for (int k = 0; k < NK; ++k) {
-            if (TFQMRGPU_PROF_PROBE == k && last.nprobes == nprobes_before) continue; // gated off: empty launches
+            bool const gated = (TFQMRGPU_PROF_PROBE == k && last.nprobes == nprobes_before); // probe not requested
             float ms = 0;
             if (hipSuccess == hipEventElapsedTime(&ms, pev[slot * (NK + 1) + k], pev[slot * (NK + 1) + k + 1])) {
-                p.profMs[k] += ms; p.profLaunches[k] += 1;
+                if (gated) { p.profGatedMs[k] += ms; p.profGatedLaunches[k] += 1; }
+                else { p.profMs[k] += ms; p.profLaunches[k] += 1; }
             }
         }
         if (last.state != 0) break;
         if (enq < maxIt) { enqueue(enq % DEPTH); ++enq; }
     }
     (void)hipStreamSynchronize(s);
+    // iterations that were enqueued ahead and found the solve finished: their launches return at once
+    if (prof) for (; seen < enq; ++seen) {
+        int const slot = seen % DEPTH;
+        for (int k = 0; k < NK; ++k) {
+            float ms = 0;
+            if (hipSuccess == hipEventElapsedTime(&ms, pev[slot * (NK + 1) + k], pev[slot * (NK + 1) + k + 1])) {
+                p.profGatedMs[k] += ms; p.profGatedLaunches[k] += 1;
+            }
+        }
+    }
     if (hipSuccess != hipGetLastError() && !fail) fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
     for (auto& e : ev) (void)hipEventDestroy(e);
     for (auto& e : pev) (void)hipEventDestroy(e);
@@ -607,6 +618,13 @@ tfqmrgpuStatus_t tfqmrgpuExt_getProfile(tfqmrgpuBsrsvPlan_t plan, int64_t* launc
     auto p = asPlan(plan);
     if (!p || !launches || !milliseconds) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
     for (int k = 0; k < TFQMRGPU_PROFILE_CLASSES; ++k) { launches[k] = p->profLaunches[k]; milliseconds[k] = p->profMs[k]; }
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+tfqmrgpuStatus_t tfqmrgpuExt_getProfileGated(tfqmrgpuBsrsvPlan_t plan, int64_t* launches, double* milliseconds) {
+    auto p = asPlan(plan);
+    if (!p || !launches || !milliseconds) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    for (int k = 0; k < TFQMRGPU_PROFILE_CLASSES; ++k) { launches[k] = p->profGatedLaunches[k]; milliseconds[k] = p->profGatedMs[k]; }
     return TFQMRGPU_STATUS_SUCCESS;
 }
 

@@ -93,6 +93,8 @@ struct Plan {
     bool profiling = false;
     int64_t profLaunches[16] = {};
     double profMs[16] = {};
+    int64_t profGatedLaunches[16] = {};   // launches that found the solve stopped / no probe requested
+    double profGatedMs[16] = {};
 
     size_t nPairs() const { return pairs.size() / 2; }
 };

@@ -19,6 +19,8 @@
 // A work group processes one chunk (run of Y blocks of one block column, tfq_plan.cpp), so the
 // per-RHS scalars of the epilogue are uniform and the dot / norm contributions leave the work group
 // as one [LN] record (deterministic order).
+#include <cstdlib>
+
 #include "tfq_device.hpp"
 #include "tfq_vec.hpp"
 
@@ -79,6 +81,31 @@ __device__ inline void epilogue(SpmmArgs const& a, size_t off, int P, R yr, R yi
         }
         double const dr = rr, di = ri;
         acc[0] += dr * dr + di * di;
+    }
+}
+
+// the same with the epilogue operands already in registers (ur,ui: old v4|v5, xr,xi: v8, wr,wi: v3)
+template <typename R, int EPI>
+__device__ inline void epilogue_pre(SpmmArgs const& a, size_t off, int P, R yr, R yi, R sr, R si,
+                                    R ur, R ui, R xr, R xi, float wrf, float wif, double* acc)
+{
+    ((R*)a.Y)[off] = yr; ((R*)a.Y)[off + P] = yi;
+    R* e0 = (R*)a.e0;
+    double const wr = wrf, wi = wif;
+    if constexpr (EPI == EPI_XPAY_DOT) {
+        R tr = xr + sr * ur - si * ui, ti = xi + si * ur + sr * ui;
+        ur = yr + sr * tr - si * ti; ui = yi + si * tr + sr * ti;
+        e0[off] = ur; e0[off + P] = ui;
+        double const dr = ur, di = ui;
+        acc[0] += dr * wr - di * wi;
+        acc[1] += dr * wi + di * wr;
+    } else {
+        R const nr = sr * yr - si * yi + ur, ni = si * yr + sr * yi + ui;
+        e0[off] = nr; e0[off + P] = ni;
+        double const dr = nr, di = ni;
+        acc[0] += dr * wr - di * wi;
+        acc[1] += dr * wi + di * wr;
+        acc[2] += dr * dr + di * di;
     }
 }
 
@@ -218,7 +245,7 @@ struct Slice {
     }
 };
 
-template <typename R, int LM, int LN, int EPI>
+template <typename R, int LM, int LN, int EPI, bool PRE>
 __global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
     if (gate_closed(a)) return;
     static_assert(LM % 16 == 0 && LN % 16 == 0, "MFMA tiles are 16 x 16");
@@ -267,16 +294,34 @@ __global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
             o.template load<LM, LN>(A0 + size_t(a.pairs[2 * size_t(q)]) * 2 * LM * LM,
                                     X0 + size_t(a.pairs[2 * size_t(q) + 1]) * 2 * P, k0, lr);
         };
-        // software pipeline, two register sets: the loads of slice t+1 are in flight while the MFMAs of
-        // slice t issue (one wave alone keeps the matrix pipe busy; co-resident waves cover the rest)
+        // software pipeline, two register sets: the loads of slices t+1, t+2 are in flight while the MFMAs
+        // of slice t issue.  With PRE the operands of the epilogue (old v4|v5, v8, v3) are requested right
+        // behind the first two slices: vmcnt retires in order, so they must be younger than the slices
+        // whose MFMAs should start first and they have two slices of matrix work to arrive.
         Slice<R, NT, KSL> o0, o1;
         if (nT > 0) fetch(o0, 0);
+        if (nT > 1) fetch(o1, 1);
+        constexpr int NE = PRE ? NT : 1, N4 = PRE ? 4 : 1;
+        R pur[NE][N4], pui[NE][N4], pxr[NE][N4], pxi[NE][N4];
+        float pwr[NE][N4], pwi[NE][N4];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    size_t const off = size_t(y) * 2 * P + (i0 + Acc<R>::row(lane, r)) * LN + nt * 16 + lc;
+                    pur[nt][r] = ((R const*)a.e0)[off]; pui[nt][r] = ((R const*)a.e0)[off + P];
+                    if constexpr (EPI == EPI_XPAY_DOT) { pxr[nt][r] = ((R const*)a.e1)[off]; pxi[nt][r] = ((R const*)a.e1)[off + P]; }
+                    else { pxr[nt][r] = 0; pxi[nt][r] = 0; }
+                    pwr[nt][r] = a.v3[off]; pwi[nt][r] = a.v3[off + P];
+                }
+        }
         uint32_t t = 0;
         for (; t + 2 <= nT; t += 2) {
-            fetch(o1, t + 1);
             o0.mma(cre, cim);
             if (t + 2 < nT) fetch(o0, t + 2);
             o1.mma(cre, cim);
+            if (t + 3 < nT) fetch(o1, t + 3);
         }
         if (t < nT) o0.mma(cre, cim);
 
@@ -288,7 +333,9 @@ __global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
             for (int r = 0; r < 4; ++r) {
                 int const e = (i0 + Acc<R>::row(lane, r)) * LN + nt * 16 + lc;
                 double acc[NPL > 0 ? NPL : 1] = {};
-                epilogue<R, EPI>(a, size_t(y) * 2 * P + e, P, cre[nt][r], cim[nt][r], sr[nt], si[nt], bq, e, acc);
+                if constexpr (PRE) epilogue_pre<R, EPI>(a, size_t(y) * 2 * P + e, P, cre[nt][r], cim[nt][r], sr[nt], si[nt],
+                                                        pur[nt][r], pui[nt][r], pxr[nt][r], pxi[nt][r], pwr[nt][r], pwi[nt][r], acc);
+                else epilogue<R, EPI>(a, size_t(y) * 2 * P + e, P, cre[nt][r], cim[nt][r], sr[nt], si[nt], bq, e, acc);
 #pragma unroll
                 for (int p = 0; p < NPL; ++p) part[p][nt] += acc[p];
             }
@@ -320,8 +367,13 @@ __global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
 template <typename R, int LM, int LN, int EPI>
 static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
     if (0 == nWG) return;
-    if constexpr (LM % 16 == 0 && LN % 16 == 0) k_spmm_mfma<R, LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
-    else k_spmm_direct<R, LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
+    if constexpr (LM % 16 == 0 && LN % 16 == 0) {
+        // epilogue operands prefetched under the MFMAs where the registers allow it (one 16-column tile in double, two in float)
+        constexpr bool pre = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) && ((LN / 16) * sizeof(R) <= 8);
+        static int const use_pre = [] { auto v = std::getenv("TFQMRGPU_EPI_PREFETCH"); return v ? std::atoi(v) : 1; }();
+        if (pre && use_pre) k_spmm_mfma<R, LM, LN, EPI, pre><<<dim3(nWG), dim3(256), 0, s>>>(a);
+        else k_spmm_mfma<R, LM, LN, EPI, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
+    } else k_spmm_direct<R, LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
 }
 
 template <typename R, int LM, int LN>
