@@ -227,8 +227,8 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     size_t const blockElems = size_t(2) * LM * LN;
     p.S = size_t(p.nnzbX) * blockElems * p.realBytes;
 
-    // chunks: runs of blocks inside one column, sized so that a chunk of one vector is 8..64 KiB
-    // and the grid has a few thousand work groups when the problem is large enough
+    // chunks: runs of CH blocks inside one column, sized so that a chunk of one vector is 8..64 KiB and the
+    // grid has a few thousand work groups when the problem is large enough
     {
         size_t const blockBytes = blockElems * p.realBytes;
         size_t target = p.S / 4096;
@@ -236,22 +236,29 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
         uint32_t const CH = uint32_t(std::max<size_t>(1, target / blockBytes));
         auto& c = p.chunks;
         c.first.clear(); c.col.clear(); c.colPtr.assign(size_t(p.nCols) + 1, 0);
+        std::vector<uint32_t> bandOf;                        // band of CH block rows in which a chunk starts
         for (uint32_t jb = 0; jb < p.nCols; ++jb) {
             c.colPtr[jb] = uint32_t(c.col.size());
-            for (uint32_t b = p.colStart[jb]; b < p.colStart[jb + 1]; b += CH) { c.first.push_back(b); c.col.push_back(jb); }
+            for (uint32_t b = p.colStart[jb]; b < p.colStart[jb + 1]; b += CH) {
+                c.first.push_back(b); c.col.push_back(jb); bandOf.push_back(p.rowI[b] / CH);
+            }
         }
         c.colPtr[p.nCols] = uint32_t(c.col.size());
         c.first.push_back(p.nnzbX);
 
-        // Launch order of the multiply.  Work groups are dealt round-robin to the 8 XCDs (observed,
-        // used for speed only), each XCD has its own 4 MiB L2.  Chunks are sorted by
-        // (group of G block columns, band of block rows, column, row) and the sorted list is cut
-        // into 8 contiguous parts, one per XCD: inside an XCD consecutive work groups then walk down a
-        // band of rows for G columns, so X blocks shared by neighbouring rows and A blocks shared by
-        // the G columns are re-read from that L2 instead of the fabric.
-        uint32_t const n = uint32_t(c.col.size());
+        // Launch order of the multiply.  Work groups are dealt round-robin to the 8 XCDs (observed; used for
+        // speed only, never for correctness), each XCD has its own 4 MiB L2.  Chunks are sorted by
+        // (group of G block columns, band of block rows, column) and the sorted list is cut into 8
+        // contiguous parts, one per XCD: inside an XCD consecutive work groups walk down the row bands of G
+        // columns together, so the A blocks of a band are re-read from that L2 (measured on P2: fused
+        // multiply 0.92 -> 0.82 ms; larger G loses the X blocks shared by neighbouring bands).
+        // (Tried and dropped in round 1: one chunk per WAVE with the 4 waves of a work group on 4 columns
+        //  of the same band -- 20 % slower; with all A traffic removed artificially the kernel only
+        //  reaches 0.77 ms, so A re-reads are not what bounds it any more.)
         auto envu = [](char const* name, uint32_t dflt) { auto v = std::getenv(name); return v ? uint32_t(std::atoi(v)) : dflt; };
-        uint32_t const mode = envu("TFQMRGPU_ORDER", 1), G = std::max(1u, envu("TFQMRGPU_ORDER_G", 8)), band = std::max(1u, envu("TFQMRGPU_ORDER_BAND", 64));
+        uint32_t const n = uint32_t(c.col.size());
+        uint32_t const mode = envu("TFQMRGPU_ORDER", 1), G = std::max(1u, envu("TFQMRGPU_ORDER_G", 8));
+        uint32_t const BM = std::max(1u, envu("TFQMRGPU_ORDER_BANDMULT", 1));   // bands of BM*CH block rows
         std::vector<uint32_t> sorted(n);
         std::iota(sorted.begin(), sorted.end(), 0u);
         c.order = sorted;
@@ -259,10 +266,8 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
             std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b) {
                 uint32_t const ga = c.col[a] / G, gb = c.col[b] / G;
                 if (ga != gb) return ga < gb;
-                uint32_t const ba = p.rowI[c.first[a]] / band, bb = p.rowI[c.first[b]] / band;
-                if (ba != bb) return ba < bb;
-                if (c.col[a] != c.col[b]) return c.col[a] < c.col[b];
-                return a < b;
+                if (bandOf[a] / BM != bandOf[b] / BM) return bandOf[a] / BM < bandOf[b] / BM;
+                return c.col[a] < c.col[b];
             });
             uint32_t const q = n / 8, r = n % 8;
             std::vector<uint32_t> begin(9, 0);

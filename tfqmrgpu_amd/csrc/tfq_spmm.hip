@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_spmm_direct(SpmmArgs a) {
     int const g = (P >= 256) ? 0 : t / P;
     int const e0 = (P >= 256) ? t : t % P;
     bool const active = (g < GRP);
-    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    uint32_t const chunk = blockIdx.x;
     uint32_t first, last, col = 0;
     if (a.chunkFirst) { first = a.chunkFirst[chunk]; last = a.chunkFirst[chunk + 1]; col = a.chunkCol[chunk]; }
     else { first = chunk * a.CH; last = min(first + a.CH, a.nY); }
@@ -257,9 +257,9 @@ __global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
     int const lane = threadIdx.x & 63;
     int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int const lr = lane >> 4, lc = lane & 15;
-    // work groups that are dispatched to the same XCD (blockIdx % 8, observed round-robin) get
-    // neighbouring chunks (a.order), so that the X blocks shared by neighbouring block rows and the
-    // A blocks shared by neighbouring block columns are served by that XCD's L2
+    // work groups that are dispatched to the same XCD (blockIdx % 8, observed round-robin) get neighbouring
+    // chunks (a.order, tfq_plan.cpp), so that the A blocks shared by neighbouring block columns are served
+    // by that XCD's L2
     uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;
     uint32_t first, last, col = 0;
     if (a.chunkFirst) { first = a.chunkFirst[chunk]; last = a.chunkFirst[chunk + 1]; col = a.chunkCol[chunk]; }
@@ -401,7 +401,9 @@ static bool spmm_dispatch(bool dbl, int lm, int ln, int epi, SpmmArgs const& a, 
 void spmm_launch(int epi, DevPlan const& d, hipStream_t s) {
     SpmmArgs a{};
     a.A = d.A; a.starts = d.starts; a.pairs = d.pairs; a.nY = d.nnzbX;
-    a.chunkFirst = d.chunkFirst; a.chunkCol = d.chunkCol; a.order = d.order; a.CH = 0;
+    a.chunkFirst = d.chunkFirst; a.chunkCol = d.chunkCol; a.CH = 0;
+    bool const mfma = (d.LM % 16 == 0 && d.LN % 16 == 0);
+    a.order = mfma ? d.order : nullptr;
     a.ctl = d.ctl; a.v3 = d.v3; a.B = d.B; a.bOfX = d.bOfX; a.pz = d.pz; a.pd = d.pd;
     switch (epi) {
     case EPI_XPAY_DOT:     a.X = d.v6; a.Y = d.v9; a.e0 = d.v4; a.e1 = d.v8; a.sc = d.beta; a.gate = 1; break;
