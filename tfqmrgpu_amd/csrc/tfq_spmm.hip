@@ -14,8 +14,9 @@
 //    X[k0 + l/16][j0 + l%16], i.e. four consecutive 128-byte rows per load instruction, so operands go
 //    global -> VGPR fully coalesced with no LDS transpose.  4 real MFMA chains per complex product
 //    (-Im(A) is formed once per operand).
-//  * k_spmm_direct : every other block shape (LM in {4, 8}, LN in {5, 9, 10, ...}); one thread per
-//    output element, operands through the vector L1.
+//  * k_spmm_mfma8 : LM == 8, LN multiple of 8: [Re A; Im A] x [Re X | Im X] fills one 16 x 16 tile.
+//  * k_spmm_direct : every other block shape (LM == 4, LN in {9, 10}); one thread per output element,
+//    operands through the vector L1.
 // A work group processes one chunk (run of Y blocks of one block column, tfq_plan.cpp), so the
 // per-RHS scalars of the epilogue are uniform and the dot / norm contributions leave the work group
 // as one [LN] record (deterministic order).
@@ -364,6 +365,122 @@ __global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// MFMA kernel for 8-row blocks (LM == 8, LN % 8 == 0).  A 16x16 tile would be half empty, so the tile is
+// filled with the complex structure instead:   [Re A]             [Re A Re X | Re A Im X]
+//                                               [Im A] (16 x 8)  x  [Re X | Im X] (8 x 16)  =  [Im A Re X | Im A Im X]
+// i.e. all four real products of one 8x8 complex block product come out of ONE accumulator tile with
+// K = 8 -> 2 MFMAs (every flop useful).  The native layouts again are the operand layouts: lane l feeds
+// A[c = (l%16)/8][k0 + l/16][(l%16)%8] and X[c = (l%16)/8][k0 + l/16][8 nt + (l%16)%8].
+// After the pair loop the tile goes through a wave-private LDS patch and comes back as one complex
+// element per lane:  Y = (Q00 - Q11) + i (Q01 + Q10),  lane l <-> element (row l/8, column l%8).
+template <typename R, int LN, int EPI>
+__global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
+    if (gate_closed(a)) return;
+    constexpr int LM = 8, P = LM * LN, NT = LN / 8;
+    constexpr int NPL = EpiPlanes<EPI>::N;
+    static_assert(LN % 8 == 0, "8-column tiles");
+    using T4 = typename Acc<R>::T;
+    __shared__ R tile[4][16][17];                      // one patch per wave, padded rows
+    int const lane = threadIdx.x & 63;
+    int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int const lr = lane >> 4, lc = lane & 15;
+    int const part8 = lc >> 3, j8 = lc & 7;            // operand side: plane and column inside the tile
+    int const ei = lane >> 3, ej = lane & 7;           // epilogue side: element (ei, ej) of the 8 x 8 tile
+    uint32_t const chunk = blockIdx.x;
+    uint32_t first, last, col = 0;
+    if (a.chunkFirst) { first = a.chunkFirst[chunk]; last = a.chunkFirst[chunk + 1]; col = a.chunkCol[chunk]; }
+    else { first = chunk * a.CH; last = min(first + a.CH, a.nY); }
+
+    R sr[NT], si[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { sr[nt] = 0; si[nt] = 0; }
+    if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            sr[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + nt * 8 + ej];
+            si[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + nt * 8 + ej];
+        }
+    }
+    double part[NPL > 0 ? NPL : 1][NT] = {};
+
+    struct Ops { R a[2]; R x[2][NT]; };
+    R const* const A0 = (R const*)a.A + part8 * (LM * LM) + j8;      // + k*8
+    R const* const X0 = (R const*)a.X + part8 * P + j8;              // + k*LN + nt*8
+    for (uint32_t y = first + wave; y < last; y += 4) {
+        T4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = T4{0, 0, 0, 0};
+        uint32_t const q0 = a.starts[y], q1 = a.starts[y + 1];
+        auto fetch = [&](Ops& o, uint32_t q) {
+            R const* Ab = A0 + size_t(a.pairs[2 * size_t(q)]) * 2 * LM * LM;
+            R const* Xb = X0 + size_t(a.pairs[2 * size_t(q) + 1]) * 2 * P;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                int const k = 4 * s + lr;
+                o.a[s] = Ab[k * LM];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) o.x[s][nt] = Xb[k * LN + nt * 8];
+            }
+        };
+        auto mma = [&](Ops const& o) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = Acc<R>::mma(o.a[s], o.x[s][nt], acc[nt]);
+        };
+        Ops o0, o1;
+        if (q0 < q1) fetch(o0, q0);
+        if (q0 + 1 < q1) fetch(o1, q0 + 1);
+        uint32_t q = q0;
+        for (; q + 2 <= q1; q += 2) {
+            mma(o0);
+            if (q + 2 < q1) fetch(o0, q + 2);
+            mma(o1);
+            if (q + 3 < q1) fetch(o1, q + 3);
+        }
+        if (q < q1) mma(o0);
+
+        uint32_t bq = 0xffffffffu;
+        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[wave][Acc<R>::row(lane, r)][lc] = acc[nt][r];
+            __builtin_amdgcn_wave_barrier();           // LDS operations of one wave complete in order
+            R const yr = tile[wave][ei][ej] - tile[wave][ei + 8][ej + 8];
+            R const yi = tile[wave][ei][ej + 8] + tile[wave][ei + 8][ej];
+            int const e = ei * LN + nt * 8 + ej;
+            double accp[NPL > 0 ? NPL : 1] = {};
+            epilogue<R, EPI>(a, size_t(y) * 2 * P + e, P, yr, yi, sr[nt], si[nt], bq, e, accp);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) part[p][nt] += accp[p];
+        }
+    }
+
+    if constexpr (NPL > 0) {
+        // the 8 rows of a column sit 8 lanes apart: add them, then the four waves in order
+        __shared__ double s[4][NPL][LN];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                double v = part[p][nt];
+                v += __shfl_xor(v, 8);
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (lane < 8) s[wave][p][nt * 8 + lane] = v;
+            }
+        __syncthreads();
+        for (int e = threadIdx.x; e < NPL * LN; e += 256) {
+            int const p = e / LN, j = e % LN;
+            double const sum = ((s[0][p][j] + s[1][p][j]) + s[2][p][j]) + s[3][p][j];
+            write_record<EPI>(a, chunk, LN, p, j, sum);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 template <typename R, int LM, int LN, int EPI>
 static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
     if (0 == nWG) return;
@@ -373,7 +490,8 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
         static int const use_pre = [] { auto v = std::getenv("TFQMRGPU_EPI_PREFETCH"); return v ? std::atoi(v) : 1; }();
         if (pre && use_pre) k_spmm_mfma<R, LM, LN, EPI, pre><<<dim3(nWG), dim3(256), 0, s>>>(a);
         else k_spmm_mfma<R, LM, LN, EPI, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
-    } else k_spmm_direct<R, LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
+    } else if constexpr (LM == 8 && LN % 8 == 0) k_spmm_mfma8<R, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
+    else k_spmm_direct<R, LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
 }
 
 template <typename R, int LM, int LN>
@@ -426,6 +544,7 @@ tfqmrgpuStatus_t launch_multiply(char precision, int lm, int ln, uint32_t nnzbY,
     int const mt = mfma ? lm / 16 : 1;
     uint32_t ch = (mt >= 4) ? 1 : 4 / mt;                 // one 16-row strip per wave
     if (!mfma) ch = (lm * ln >= 256) ? 1 : 256 / (lm * ln); // one Y block per thread group
+    if (8 == lm && ln % 8 == 0) ch = 4;                     // k_spmm_mfma8: one Y block per wave
     a.CH = ch;
     uint32_t const nWG = (nnzbY + ch - 1) / ch;
     if (!spmm_dispatch(dbl, lm, ln, EPI_NONE, a, nWG, s))

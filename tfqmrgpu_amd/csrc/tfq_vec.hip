@@ -243,12 +243,27 @@ __global__ __launch_bounds__(256) void k_x_flush(DevPlan d) {
 // then run the scalar update for the LN right-hand sides of the column.
 template <int LN, int NPL>
 __device__ inline void column_sum(double const* part, uint32_t c0, uint32_t c1, double* s, double (&res)[NPL]) {
-    constexpr int G = 256 / LN;
+    constexpr int G = 256 / LN;      // lane groups: group g takes records c0+g, c0+g+G, ...
+    constexpr int U = 8;             // records in flight per lane (independent loads; the order of the sum stays fixed)
     int const t = threadIdx.x, g = t / LN, j = t % LN;
     double acc[NPL] = {};
-    if (g < G) for (uint32_t c = c0 + g; c < c1; c += G)
+    if (g < G) {
+        uint32_t c = c0 + g;
+        for (; c + (U - 1) * G < c1; c += U * G) {
+            double v[U][NPL];
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) acc[p] += part[(size_t(c) * NPL + p) * LN + j];
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) v[u][p] = part[(size_t(c + u * G) * NPL + p) * LN + j];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) acc[p] += v[u][p];
+        }
+        for (; c < c1; c += G)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) acc[p] += part[(size_t(c) * NPL + p) * LN + j];
+    }
     __syncthreads();
     if (g < G)
 #pragma unroll
