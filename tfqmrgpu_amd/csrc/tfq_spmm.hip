@@ -428,17 +428,21 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[nt] = Acc<R>::mma(o.a[s], o.x[s][nt], acc[nt]);
         };
-        Ops o0, o1;
-        if (q0 < q1) fetch(o0, q0);
-        if (q0 + 1 < q1) fetch(o1, q0 + 1);
-        uint32_t q = q0;
-        for (; q + 2 <= q1; q += 2) {
-            mma(o0);
-            if (q + 2 < q1) fetch(o0, q + 2);
-            mma(o1);
-            if (q + 3 < q1) fetch(o1, q + 3);
+        // the block products are tiny (2 MFMAs, 2 KiB of operands): keep DEPTH of them in flight
+        constexpr int DEPTH = (NT <= 2) ? 4 : 2;
+        Ops o[DEPTH];
+        uint32_t const nq = q1 - q0;
+#pragma unroll
+        for (int dd = 0; dd < DEPTH; ++dd) if (uint32_t(dd) < nq) fetch(o[dd], q0 + dd);
+        for (uint32_t base = 0; base < nq; base += DEPTH) {
+#pragma unroll
+            for (int dd = 0; dd < DEPTH; ++dd) {
+                if (base + dd < nq) {
+                    mma(o[dd]);
+                    if (base + dd + DEPTH < nq) fetch(o[dd], q0 + base + dd + DEPTH);
+                }
+            }
         }
-        if (q < q1) mma(o0);
 
         uint32_t bq = 0xffffffffu;
         if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
