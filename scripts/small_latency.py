@@ -2,12 +2,13 @@
 """wall time of repeated solves of a small system (launch/latency-bound regime)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
+import numpy as np, torch
 import tfqmrgpu_amd as T
 from tfqmrgpu_amd.fd_generator import FDExample
 for args in [(6, 24, 4, 2, -0.25, 4), (1.75, 6.75, 2, 3, 0.0, 4), (10, 60, 4, 2, 0.0, 4)]:
     pr = FDExample(*args).problem()
-    with T.Solver() as s:
+    stream = torch.cuda.Stream()
+    with T.Solver(stream.cuda_stream) as s:
         s.create_plan(pr); s.set_buffer(nbytes=s.buffer_size(pr.LM, pr.LN, "z"))
         s.set_matrix("A", pr.A); s.set_matrix("B", pr.B)
         s.solve(pr.tolerance, 2000)

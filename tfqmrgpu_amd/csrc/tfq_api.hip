@@ -161,12 +161,16 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
     DevPlan const d = resolve(p);
     bool const multi = (h.comm != nullptr) || (h.reduceFn != nullptr);
 
-    constexpr int DEPTH = 4;
+    constexpr int DEPTH = Plan::kDepth;
     constexpr int NK = TFQMRGPU_PROFILE_CLASSES;
-    Ctl* ring = nullptr;
-    TFQ_HIP(hipHostMalloc((void**)&ring, DEPTH * sizeof(Ctl), hipHostMallocDefault), TFQMRGPU_STATUS_ALLOCATION_FAILED)
+    // pinned ring + events live with the plan (hipHostMalloc / event creation cost more than a small solve)
+    if (!p.ring) {
+        TFQ_HIP(hipHostMalloc((void**)&p.ring, DEPTH * sizeof(Ctl), hipHostMallocDefault), TFQMRGPU_STATUS_ALLOCATION_FAILED)
+        for (auto& e : p.ringEvent) { hipEvent_t ev_; (void)hipEventCreateWithFlags(&ev_, hipEventDisableTiming); e = (void*)ev_; }
+    }
+    Ctl* const ring = (Ctl*)p.ring;
     hipEvent_t ev[DEPTH];
-    for (auto& e : ev) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    for (int i = 0; i < DEPTH; ++i) ev[i] = (hipEvent_t)p.ringEvent[i];
     // profiling: NK+1 timing events per in-flight iteration, event k sits in front of kernel class k
     bool const prof = p.profiling;
     std::vector<hipEvent_t> pev(prof ? DEPTH * (NK + 1) : 0);
@@ -178,7 +182,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
     vec_launch(VEC_SETUP, d, tol, maxIt, s);
 
     tfqmrgpuStatus_t fail = TFQMRGPU_STATUS_SUCCESS;
-    auto enqueue = [&](int slot) {
+    auto launches = [&](int slot) {            // all kernels of one iteration slot (most of them gate themselves off)
         auto mark = [&](int k) { if (prof) (void)hipEventRecord(pev[slot * (NK + 1) + k], s); };
         mark(TFQMRGPU_PROF_DEC35);            vec_launch(VEC_DEC35, d, 0, 0, s);
         mark(TFQMRGPU_PROF_XPAY_V6);          vec_launch(VEC_XPAY_V6, d, 0, 0, s);
@@ -205,6 +209,9 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
             launch_probe_decide(d, 2, s);
         } else launch_probe_decide(d, 0, s);
         mark(NK);
+    };
+    auto enqueue = [&](int slot) {
+        launches(slot);
         (void)hipMemcpyAsync(&ring[slot], d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s);
         (void)hipEventRecord(ev[slot], s);
     };
@@ -243,9 +250,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         }
     }
     if (hipSuccess != hipGetLastError() && !fail) fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
-    for (auto& e : ev) (void)hipEventDestroy(e);
     for (auto& e : pev) (void)hipEventDestroy(e);
-    (void)hipHostFree(ring);
     if (fail) return fail;
 
     // flop model of the reference: tfqmrgpu_linalg.hxx:587,625,684,703 and tfqmrgpu_blocksparse.hxx:198
@@ -355,6 +360,7 @@ tfqmrgpuStatus_t tfqmrgpu_bsrsv_destroyPlan(tfqmrgpuHandle_t handle, tfqmrgpuBsr
     (void)handle;
     auto p = asPlan(plan);
     if (!p) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    if (p->ring) { (void)hipHostFree(p->ring); for (auto e : p->ringEvent) (void)hipEventDestroy((hipEvent_t)e); }
     p->magic = 0;
     delete p;
     return TFQMRGPU_STATUS_SUCCESS;

@@ -83,6 +83,9 @@ struct Plan {
     Window wStarts, wPairs, wSubset, wBColPtr, wBList, wU2I, wRowI;
 
     char* buffer = nullptr;            // device buffer registered by setBuffer
+    static constexpr int kDepth = 4;   // iterations the host keeps enqueued ahead of the stopping decision
+    void* ring = nullptr;              // pinned copies of the control block, one per in-flight iteration
+    void* ringEvent[kDepth] = {};      // hipEvent_t behind each copy
     int shadowMode = TFQMRGPU_SHADOW_HASH;
     bool haveB = false;
 
