@@ -119,8 +119,12 @@ def main():
         raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"
     torch.cuda.set_device(local)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the multi-rank path is taken even for one rank, so that it can be
+    # exercised on a single-GPU box: process group, RCCL communicator, all-reduced stopping test
+    distributed = (world > 1) or ("RANK" in os.environ and os.environ.get("TFQMRGPU_BENCH_FORCE_DIST", "1") == "1")
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import tfqmrgpu_amd as T
@@ -135,7 +139,7 @@ def main():
         s.set_buffer(device_ptr=buf.data_ptr())
         s.set_matrix("A", pr.A)
         s.set_matrix("B", pr.B)
-        if world > 1:  # RCCL communicator of the stopping test: id from rank 0, broadcast with torch.distributed
+        if distributed:  # RCCL communicator of the stopping test: id from rank 0, broadcast with torch.distributed
             uid = (C.c_char * 128)()
             if rank == 0:
                 T._check(T.lib.tfqmrgpuExt_commUniqueId(uid), "tfqmrgpuExt_commUniqueId")
@@ -146,7 +150,7 @@ def main():
 
         def barrier():
             torch.cuda.synchronize()
-            if world > 1:
+            if distributed:
                 dist.barrier()
                 torch.cuda.synchronize()
 
@@ -173,7 +177,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         s.set_profiling(False)
-        if world > 1:
+        if distributed:
             red = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(red, op=dist.ReduceOp.MAX)
             elapsed = float(red.item())
@@ -253,7 +257,7 @@ def main():
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(pr, prec, min(16, os.cpu_count() or 1))
         s.close()
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:

@@ -244,6 +244,39 @@ def test_solve_all_block_sizes(oracle, prec, size):
     assert np.abs(X - X0).max() <= _tol(prec) * np.abs(X0).max()
 
 
+@pytest.mark.parametrize("prec", ["z", "c"])
+def test_one_call_driver(prec):
+    # tfqmrgpu_bsrsv_z / _c the way the reference's Julia and Python examples call them
+    # (example/tfqmrgpu_Julia_example.jl:88-120, example/tfqmrgpu_python_example.py:40-67)
+    pr = PR.julia_kat()
+    real, cplx = (np.float64, np.complex128) if prec == "z" else (np.float32, np.complex64)
+    A = np.ascontiguousarray(pr.A.astype(cplx))
+    B = np.ascontiguousarray(pr.B.astype(cplx))
+    X = np.zeros((pr.nnzbX, pr.LM, pr.LN), dtype=cplx)
+    it = C.c_int32(210)
+    res = C.c_float(1.2e-8 if prec == "z" else 1.2e-5)
+    fn = T.lib.tfqmrgpu_bsrsv_z if prec == "z" else T.lib.tfqmrgpu_bsrsv_c
+    st = fn(pr.mb, pr.LM, pr.LN, T._ptr(pr.rowPtrA), pr.nnzbA, T._ptr(pr.colIndA), T._ptr(A), b"n",
+            T._ptr(pr.rowPtrX), pr.nnzbX, T._ptr(pr.colIndX), T._ptr(X), b"n",
+            T._ptr(pr.rowPtrB), pr.nnzbB, T._ptr(pr.colIndB), T._ptr(B), b"n", C.byref(it), C.byref(res), 0, 0)
+    assert st == 0 and 0 < it.value <= 12
+    assert res.value <= (1.2e-8 if prec == "z" else 1.2e-5)
+    line = np.arange(1, 8) / 8.0
+    assert np.abs(X[:, 0, 0] - line).max() < (1e-9 if prec == "z" else 1e-4)
+    assert np.abs(X[:, 0, 4] - 1j * line).max() < (1e-9 if prec == "z" else 1e-4)   # fifth RHS carries the phase i
+    # Fortran indices through the same entry point
+    st = fn(pr.mb, pr.LM, pr.LN, T._ptr(pr.rowPtrA + 1), pr.nnzbA, T._ptr(pr.colIndA + 1), T._ptr(A), b"n",
+            T._ptr(pr.rowPtrX + 1), pr.nnzbX, T._ptr(pr.colIndX + 1), T._ptr(X), b"n",
+            T._ptr(pr.rowPtrB + 1), pr.nnzbB, T._ptr(pr.colIndB + 1), T._ptr(B), b"n", C.byref(it), C.byref(res), 1, 0)
+    assert st == 0 and np.abs(X[:, 0, 0] - line).max() < (1e-9 if prec == "z" else 1e-4)
+    # an unsupported block shape comes back as 12 with LM / LN in the word (tfqmrgpu.cu:70)
+    it = C.c_int32(10)
+    st = fn(pr.mb, 3, 3, T._ptr(pr.rowPtrA), pr.nnzbA, T._ptr(pr.colIndA), T._ptr(A), b"n",
+            T._ptr(pr.rowPtrX), pr.nnzbX, T._ptr(pr.colIndX), T._ptr(X), b"n",
+            T._ptr(pr.rowPtrB), pr.nnzbB, T._ptr(pr.colIndB), T._ptr(B), b"n", C.byref(it), C.byref(res), 0, 0)
+    assert T.decode(st) == (12, 3, 3)
+
+
 def test_plan_reuse_and_status_codes():
     pr = load_problem("fd_16x16_small")
     with T.Solver() as s:
