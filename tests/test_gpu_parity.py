@@ -264,7 +264,9 @@ def test_one_call_driver(prec):
     line = np.arange(1, 8) / 8.0
     assert np.abs(X[:, 0, 0] - line).max() < (1e-9 if prec == "z" else 1e-4)
     assert np.abs(X[:, 0, 4] - 1j * line).max() < (1e-9 if prec == "z" else 1e-4)   # fifth RHS carries the phase i
-    # Fortran indices through the same entry point
+    # Fortran indices through the same entry point (iterations / residual are in-out arguments: reset them)
+    it = C.c_int32(210)
+    res = C.c_float(1.2e-8 if prec == "z" else 1.2e-5)
     st = fn(pr.mb, pr.LM, pr.LN, T._ptr(pr.rowPtrA + 1), pr.nnzbA, T._ptr(pr.colIndA + 1), T._ptr(A), b"n",
             T._ptr(pr.rowPtrX + 1), pr.nnzbX, T._ptr(pr.colIndX + 1), T._ptr(X), b"n",
             T._ptr(pr.rowPtrB + 1), pr.nnzbB, T._ptr(pr.colIndB + 1), T._ptr(B), b"n", C.byref(it), C.byref(res), 1, 0)
