@@ -367,3 +367,60 @@ def test_large_problem_properties(torch_cuda, oracle):
         mult(Z, Y2)
         mult(2.5 * Xn + Z, Y3)
         assert (Y3 - (2.5 * Y + Y2)).abs().max().item() <= 1e-11 * Y3.abs().max().item()
+
+
+def test_edge_single_block_system(oracle):
+    # the Fortran example's first case: one 32x32 block (example/tfqmrgpu_Fortran_example.F90:22-46)
+    rng = np.random.default_rng(11)
+    A = (rng.standard_normal((1, 32, 32)) + 1j * rng.standard_normal((1, 32, 32))) / 8 + 2 * np.eye(32)
+    B = rng.standard_normal((1, 32, 32)) + 1j * rng.standard_normal((1, 32, 32))
+    pr = T.Problem([0, 1], [0], A, [0, 1], [0], [0, 1], [0], B, None, 1e-10)
+    st, X, info = T.solve_problem(pr, "z", max_iterations=300)
+    assert st == 0 and np.abs(X[0] - np.linalg.solve(A[0], B[0])).max() < 1e-8
+
+
+def test_edge_column_gaps_and_offsets(oracle):
+    # block columns 3, 7, 20 (gaps are compressed away, tfqmrgpu.cu:254-315) give the result of columns 0, 1, 2
+    pr = PR.stencil_2d(5, 4, 8, 8, 3, seed=13, radius=2.2)
+    remap = np.array([3, 7, 20])
+    gap = T.Problem(pr.rowPtrA, pr.colIndA, pr.A, pr.rowPtrX, remap[pr.colIndX], pr.rowPtrB, remap[pr.colIndB], pr.B, None, 1e-9)
+    st0, X0, i0 = T.solve_problem(pr, "z", shadow_mode=T.SHADOW_GLIBC_RAND)
+    st1, X1, i1 = T.solve_problem(gap, "z", shadow_mode=T.SHADOW_GLIBC_RAND)
+    assert st0 == st1 == 0 and i0["iterations"] == i1["iterations"] and np.array_equal(X0, X1)
+    with T.Solver() as s:
+        s.create_plan(gap)
+        assert list(s.plan_view()["original_bsrColIndX"]) == [3, 7, 20]
+
+
+def test_edge_zero_right_hand_side_column(oracle):
+    # one RHS of a block column is identically zero: |b| = 0 -> tau = 0 -> that RHS stops with status -3
+    # (tfqmrgpu_linalg.hxx:209-212), its bound is NaN and ignored by the max (tfqmrgpu_core.hxx:243); the
+    # other right-hand sides converge as usual.  The HIP path must take the same decisions as the oracle.
+    pr = PR.stencil_2d(4, 4, 4, 8, 2, seed=17, radius=2.0)
+    pr.B[:, :, 5] = 0
+    st, X, info = T.solve_problem(pr, "z", threshold=1e-9, max_iterations=100, shadow_mode=T.SHADOW_GLIBC_RAND)
+    st0, X0, info0 = oracle.solve(pr, "z", threshold=1e-9, max_iterations=100)
+    assert st == st0 and info["iterations"] == info0["iterations"]
+    keep = [j for j in range(8) if j != 5]
+    assert np.abs(X[:, :, keep] - X0[:, :, keep]).max() <= 1e-7 * np.abs(X0[:, :, keep]).max()
+    assert np.array_equal(np.isnan(X[:, :, 5]), np.isnan(X0[:, :, 5]))
+
+
+def test_edge_rows_without_blocks(torch_cuda, oracle):
+    # Y blocks whose pair list is empty must come out as zeros, for every kernel family
+    torch = torch_cuda
+    for LM, LN in ((16, 16), (8, 8), (4, 5)):
+        rng = np.random.default_rng(LM + LN)
+        nY = 9
+        starts = np.array([0, 0, 2, 2, 2, 5, 5, 5, 5, 6], np.uint32)
+        pairs = rng.integers(0, 4, size=12).astype(np.uint32)
+        A = rng.uniform(-1, 1, (4, 2, LM, LM)); X = rng.uniform(-1, 1, (nY, 2, LM, LN))
+        want = oracle.spmm("z", LM, LN, starts, pairs, A, X)
+        dA, dX = torch.from_numpy(A).cuda(), torch.from_numpy(X).cuda()
+        dS, dP = torch.from_numpy(starts.view(np.int32)).cuda(), torch.from_numpy(pairs.view(np.int32)).cuda()
+        dY = torch.full((nY, 2, LM, LN), 3.0, dtype=torch.float64, device="cuda")
+        with T.Solver() as s:
+            assert T.lib.tfqmrgpuExt_multiply(s.handle, b"z", LM, LN, nY, dS.data_ptr(), dP.data_ptr(), dA.data_ptr(), dX.data_ptr(), dY.data_ptr()) == 0
+            torch.cuda.synchronize()
+        got = dY.cpu().numpy()
+        assert np.abs(got - want).max() < 1e-12 and np.all(got[[0, 2, 3, 5, 6, 7]] == 0)
