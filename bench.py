@@ -45,6 +45,12 @@ def build_problem(name, rank):
     elif name == "stencil2d_8x8_z":     # BASELINE configs[4]: 8x8 complex<double>, ~5 nnz/row
         pr = PR.stencil_2d(256, 256, 8, 8, 8, seed=5)
         prec, desc = "z", "5-point block stencil 256x256, 8x8 complex<double>, 8 block columns"
+    elif name.startswith("st:"):        # st:LM:LN:prec:nx:ny:ncols  (5-point block stencil, X dense in ncols block columns)
+        _, lm, ln, prec, nx, ny, nc = name.split(":")
+        pr = PR.stencil_2d(int(nx), int(ny), int(lm), int(ln), int(nc), seed=7)
+        if prec == "c":
+            pr.tolerance = 1e-4
+        desc = "5-point block stencil %sx%s, %sx%s complex<%s>, %s block columns" % (nx, ny, lm, ln, "double" if prec == "z" else "float", nc)
     else:
         raise SystemExit("unknown workload " + name)
     ncols = int(pr.colIndX.max()) + 1

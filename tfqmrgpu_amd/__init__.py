@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtfQMRgpu.so")
+LIB_PATH = os.environ.get("TFQMRGPU_LIB", os.path.join(_HERE, "lib", "libtfQMRgpu.so"))   # override for A/B builds
 
 LAYOUT_RRRRIIII, LAYOUT_RRIIRRII, LAYOUT_RIRIRIRI = 0x0F, 0x33, 0x55
 SHADOW_HASH, SHADOW_GLIBC_RAND = 0, 1
