@@ -112,6 +112,24 @@ tfqmrgpuStatus_t tfqmrgpuExt_commDestroy(tfqmrgpuHandle_t handle);
 typedef void (*tfqmrgpuReduceMax_t)(void *ctx, double *values, int n);
 tfqmrgpuStatus_t tfqmrgpuExt_setReduceCallback(tfqmrgpuHandle_t handle, tfqmrgpuReduceMax_t fn, void *ctx);
 
+/* ---- (5) user-defined linear operator --------------------------------------------------- */
+/* The reference lets C++ users replace the block-sparse operator by their own `action_t` class whose
+ * `multiply(y, x, colindx, nnzbX, nCols, l2nX, streamId)` returns the flop count (README.md:110-117,
+ * tfqmrgpu_blocksparse.hxx:71-199, called at tfqmrgpu_core.hxx:134).  The C-ABI counterpart: a callback
+ * that ENQUEUES Y = A*X on `stream` (no synchronisation) for device vectors in the caller's own BSR block
+ * order of X and the native layout Y|X[nnzbX][2][lm][ln]; colindx_d[nnzbX] is the compressed block column
+ * of every block (what the reference hands over).  *flops receives the operation count of the call.
+ * A non-zero return value aborts the solve and is returned by tfqmrgpu_bsrsv_solve.
+ * With an operator installed the solver runs its un-fused schedule (gather into the caller's order,
+ * callback, vector-update kernel) and synchronises with the host once per iteration, like the reference;
+ * createPlan still needs a pattern for A (any valid one, e.g. block-diagonal), its values are not used.
+ * Two X-shaped scratch vectors are allocated by the library at the first solve and released by
+ * destroyPlan.  multiply == NULL restores the built-in block-sparse operator. */
+typedef tfqmrgpuStatus_t (*tfqmrgpuOperator_t)(void *ctx, void *Y_d, void const *X_d,
+    uint16_t const *colindx_d, uint32_t nnzbX, uint32_t nCols, int lm, int ln, char precision,
+    tfqmrgpuStream_t stream, double *flops);
+tfqmrgpuStatus_t tfqmrgpuExt_setOperator(tfqmrgpuBsrsvPlan_t plan, tfqmrgpuOperator_t multiply, void *ctx);
+
 #ifdef __cplusplus
 }
 #endif

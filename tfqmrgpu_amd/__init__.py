@@ -35,7 +35,7 @@ EXT_SYMBOLS = [  # include/tfqmrgpu_ext.h
     "tfqmrgpuExt_setShadowMode",
     "tfqmrgpuExt_setShadowVector", "tfqmrgpuExt_multiply", "tfqmrgpuExt_shardColumns",
     "tfqmrgpuExt_freeShard", "tfqmrgpuExt_commUniqueId", "tfqmrgpuExt_commInit",
-    "tfqmrgpuExt_commDestroy", "tfqmrgpuExt_setReduceCallback",
+    "tfqmrgpuExt_commDestroy", "tfqmrgpuExt_setReduceCallback", "tfqmrgpuExt_setOperator",
 ]
 FORTRAN_SYMBOLS = [  # tfqmrgpu_amd/csrc/tfq_fortran.c
     "tfqmrgpuprinterror_", "tfqmrgpucreatehandle_", "tfqmrgpudestroyhandle_", "tfqmrgpusetstream_",
@@ -64,6 +64,9 @@ class Shard(C.Structure):
 
 
 REDUCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+# tfqmrgpuOperator_t: (ctx, Y_d, X_d, colindx_d, nnzbX, nCols, lm, ln, precision, stream, *flops) -> status
+OPERATOR_CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                          C.c_int, C.c_int, C.c_char, C.c_void_p, C.POINTER(C.c_double))
 
 
 def load_library(path=LIB_PATH):
@@ -119,6 +122,7 @@ def load_library(path=LIB_PATH):
     lib.tfqmrgpuExt_commInit.argtypes = [P, I, I, P]
     lib.tfqmrgpuExt_commDestroy.argtypes = [P]
     lib.tfqmrgpuExt_setReduceCallback.argtypes = [P, REDUCE_CB, P]
+    lib.tfqmrgpuExt_setOperator.argtypes = [P, OPERATOR_CB, P]
     return lib
 
 
@@ -259,6 +263,23 @@ class Solver:
         """returns the raw status: 0 converged, 9 max iterations, 6 breakdown (tfqmrgpu_core.hxx:170,258,297)"""
         st = lib.tfqmrgpu_bsrsv_solve(self.handle, self.plan, threshold, max_iterations)
         return _check(st, "tfqmrgpu_bsrsv_solve", allowed=(0, 6, 9))
+
+    def set_operator(self, multiply):
+        """user-defined operator (tfqmrgpu_ext.h section 5): multiply(Y_ptr, X_ptr, colindx_ptr, nnzbX, nCols, lm, ln,
+        precision, stream) enqueues Y = A*X on device data in the caller's block order and returns the flop count;
+        None restores the built-in block-sparse operator"""
+        if multiply is None:
+            self._operator = OPERATOR_CB(0)
+        else:
+            def thunk(ctx, y, x, colindx, nnzbX, nCols, lm, ln, precision, stream, flops):
+                try:
+                    flops[0] = float(multiply(y, x, colindx, nnzbX, nCols, lm, ln, precision.decode(), stream) or 0.)
+                    return 0
+                except Exception:                   # an exception must not unwind through the C frames
+                    import traceback; traceback.print_exc()
+                    return 14
+            self._operator = OPERATOR_CB(thunk)     # keep the thunk alive as long as the plan may call it
+        _check(lib.tfqmrgpuExt_setOperator(self.plan, self._operator, None), "tfqmrgpuExt_setOperator")
 
     def get_info(self):
         r, f, fa, it = C.c_double(0), C.c_double(0), C.c_double(0), C.c_int32(0)

@@ -182,36 +182,72 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
     vec_launch(VEC_SETUP, d, tol, maxIt, s);
 
     tfqmrgpuStatus_t fail = TFQMRGPU_STATUS_SUCCESS;
-    auto launches = [&](int slot) {            // all kernels of one iteration slot (most of them gate themselves off)
+
+    // user-defined operator (tfqmrgpu_ext.h section 5): gather the operand into the caller's block order,
+    // let the callback enqueue Y = A*X, apply the fused epilogue to the product
+    auto const userOp = (tfqmrgpuOperator_t)p.opFn;
+    double userFlops = 0;
+    size_t const vecBytes = size_t(p.nnzbX) * 2 * p.LM * p.LN * (d.dbl ? 8 : 4);
+    auto const up256 = [](size_t n) { return (n + 255) & ~size_t(255); };
+    if (userOp && !p.opScratch) {
+        size_t const bytes = 2 * up256(vecBytes) + up256(size_t(p.nnzbX) * 4) + up256(size_t(p.nnzbX) * 2);
+        TFQ_HIP(hipMalloc((void**)&p.opScratch, bytes ? bytes : 256), TFQMRGPU_STATUS_ALLOCATION_FAILED)
+        char* const q = p.opScratch + 2 * up256(vecBytes);
+        std::vector<uint16_t> cu(p.nnzbX);      // compressed block column per block, caller's order
+        for (uint32_t u = 0; u < p.nnzbX; ++u) cu[u] = p.colindx[u];
+        TFQ_HIP(hipMemcpyAsync(q, p.i2u.data(), size_t(p.nnzbX) * 4, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        TFQ_HIP(hipMemcpyAsync(q + up256(size_t(p.nnzbX) * 4), cu.data(), size_t(p.nnzbX) * 2, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)   // cu goes out of scope
+    }
+    auto multiply = [&](int epi) {
+        if (!userOp) { spmm_launch(epi, d, s); return; }
+        char* const xu = p.opScratch; char* const yu = xu + up256(vecBytes);
+        auto const i2u = (uint32_t const*)(yu + up256(vecBytes));
+        auto const colU = (uint16_t const*)((char const*)i2u + up256(size_t(p.nnzbX) * 4));
+        launch_convert(1, d.dbl, (EPI_RESIDUAL == epi) ? d.x : d.v6, xu, d.u2i, 0, p.nnzbX, p.LM, p.LN,
+                       TFQMRGPU_LAYOUT_RRRRIIII, false, false, s);
+        double fl = 0;
+        auto const st = userOp(p.opCtx, yu, xu, colU, p.nnzbX, p.nCols, p.LM, p.LN, p.precision, (tfqmrgpuStream_t)s, &fl);
+        if (st && !fail) fail = st;
+        userFlops += fl;
+        epilogue_launch(epi, d, yu, i2u, s);
+    };
+
+    // part 0: all kernels of one iteration slot (most of them gate themselves off); 1: without the probe; 2: probe only
+    auto launches = [&](int slot, int part) {
         auto mark = [&](int k) { if (prof) (void)hipEventRecord(pev[slot * (NK + 1) + k], s); };
-        mark(TFQMRGPU_PROF_DEC35);            vec_launch(VEC_DEC35, d, 0, 0, s);
-        mark(TFQMRGPU_PROF_XPAY_V6);          vec_launch(VEC_XPAY_V6, d, 0, 0, s);
-        mark(TFQMRGPU_PROF_SPMM_V4_DOT);      spmm_launch(EPI_XPAY_DOT, d, s);
-        mark(TFQMRGPU_PROF_DEC34);            vec_launch(VEC_DEC34, d, 0, 0, s);
-        mark(TFQMRGPU_PROF_V5_NRM);           vec_launch(VEC_V5_NRM, d, 0, 0, s);
-        mark(TFQMRGPU_PROF_DECT_C67);         vec_launch(VEC_DECT_C67, d, 0, 0, s);
-        mark(TFQMRGPU_PROF_X_V6_V7);          vec_launch(VEC_X_V6_V7, d, 0, 0, s);
-        mark(TFQMRGPU_PROF_SPMM_V5_NRM_DOT);  spmm_launch(EPI_AXPY_NRM_DOT, d, s);
-        mark(TFQMRGPU_PROF_DECT_FINAL);       vec_launch(VEC_DECT_FIN, d, 0, 0, s);
-        mark(TFQMRGPU_PROF_DECIDE);
-        if (multi) {
-            launch_decide(d, 1, s);
-            auto const st = reduce_over_ranks(h, d, 0, s); if (st) fail = st;
-            launch_decide(d, 2, s);
-        } else launch_decide(d, 0, s);
-        mark(TFQMRGPU_PROF_PROBE);
-        vec_launch(VEC_X_FLUSH, d, 0, 0, s);
-        spmm_launch(EPI_RESIDUAL, d, s);
-        vec_launch(VEC_PROBE_COL, d, 0, 0, s);
-        if (multi) {
-            launch_probe_decide(d, 1, s);
-            auto const st = reduce_over_ranks(h, d, 2, s); if (st) fail = st;
-            launch_probe_decide(d, 2, s);
-        } else launch_probe_decide(d, 0, s);
+        if (part != 2) {
+            mark(TFQMRGPU_PROF_DEC35);            vec_launch(VEC_DEC35, d, 0, 0, s);
+            mark(TFQMRGPU_PROF_XPAY_V6);          vec_launch(VEC_XPAY_V6, d, 0, 0, s);
+            mark(TFQMRGPU_PROF_SPMM_V4_DOT);      multiply(EPI_XPAY_DOT);
+            mark(TFQMRGPU_PROF_DEC34);            vec_launch(VEC_DEC34, d, 0, 0, s);
+            mark(TFQMRGPU_PROF_V5_NRM);           vec_launch(VEC_V5_NRM, d, 0, 0, s);
+            mark(TFQMRGPU_PROF_DECT_C67);         vec_launch(VEC_DECT_C67, d, 0, 0, s);
+            mark(TFQMRGPU_PROF_X_V6_V7);          vec_launch(VEC_X_V6_V7, d, 0, 0, s);
+            mark(TFQMRGPU_PROF_SPMM_V5_NRM_DOT);  multiply(EPI_AXPY_NRM_DOT);
+            mark(TFQMRGPU_PROF_DECT_FINAL);       vec_launch(VEC_DECT_FIN, d, 0, 0, s);
+            mark(TFQMRGPU_PROF_DECIDE);
+            if (multi) {
+                launch_decide(d, 1, s);
+                auto const st = reduce_over_ranks(h, d, 0, s); if (st) fail = st;
+                launch_decide(d, 2, s);
+            } else launch_decide(d, 0, s);
+            mark(TFQMRGPU_PROF_PROBE);
+        }
+        if (part != 1) {
+            vec_launch(VEC_X_FLUSH, d, 0, 0, s);
+            multiply(EPI_RESIDUAL);
+            vec_launch(VEC_PROBE_COL, d, 0, 0, s);
+            if (multi) {
+                launch_probe_decide(d, 1, s);
+                auto const st = reduce_over_ranks(h, d, 2, s); if (st) fail = st;
+                launch_probe_decide(d, 2, s);
+            } else launch_probe_decide(d, 0, s);
+        }
         mark(NK);
     };
-    auto enqueue = [&](int slot) {
-        launches(slot);
+    auto enqueue = [&](int slot, int part = 0) {
+        launches(slot, part);
         (void)hipMemcpyAsync(&ring[slot], d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s);
         (void)hipEventRecord(ev[slot], s);
     };
@@ -219,6 +255,23 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
     Ctl last{};
     last.state = (maxIt > 0) ? 0 : 3; last.residual2_reached = 1e300; last.iterations_needed = maxIt;
     int enq = 0, seen = 0;
+    if (userOp) {
+        // the callback's kernels cannot look at the control block, so nothing is enqueued ahead of a decision:
+        // one host round trip per iteration (and one per probe), like the reference (tfqmrgpu_core.hxx:235-304)
+        for (int it = 0; it < maxIt && !fail && 0 == last.state; ++it) {
+            for (int part = 1; part <= 2 && !fail; ++part) {
+                if (2 == part && !(0 == last.state && last.probe)) break;
+                enqueue(0, part);
+                if (hipSuccess != hipEventSynchronize(ev[0])) { fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED); break; }
+                last = ring[0];
+                if (1 == part) p.boundHistory.push_back(last.max_bound2);
+            }
+            if (prof) for (int k = 0; k < NK; ++k) {
+                float ms = 0;
+                if (hipSuccess == hipEventElapsedTime(&ms, pev[k], pev[k + 1])) { p.profMs[k] += ms; p.profLaunches[k] += 1; }
+            }
+        }
+    } else
     while (enq < std::min(DEPTH, maxIt)) { enqueue(enq % DEPTH); ++enq; }
     while (seen < enq && !fail) {
         int const slot = seen % DEPTH;
@@ -257,6 +310,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
     double const blk = double(p.LM) * p.LN, nX = p.nnzbX;
     double const fMult = double(p.nPairs()) * 8. * p.LM * blk, fDot = nX * 8. * blk, fNrm = nX * 4. * blk, fAxp = nX * 8. * blk;
     p.flops_performed = fNrm + last.iteration * (2 * fMult + 2 * fDot + 2 * fNrm + 10 * fAxp) + last.nprobes * (fMult + fNrm);
+    if (userOp) p.flops_performed += userFlops - (2. * last.iteration + last.nprobes) * fMult;  // the operator's own count
     p.flops_performed_all += p.flops_performed;
     p.residuum_reached = std::sqrt(last.residual2_reached);
     p.iterations_needed = (1 == last.state) ? last.iterations_needed : maxIt;
@@ -361,6 +415,7 @@ tfqmrgpuStatus_t tfqmrgpu_bsrsv_destroyPlan(tfqmrgpuHandle_t handle, tfqmrgpuBsr
     auto p = asPlan(plan);
     if (!p) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
     if (p->ring) { (void)hipHostFree(p->ring); for (auto e : p->ringEvent) (void)hipEventDestroy((hipEvent_t)e); }
+    if (p->opScratch) (void)hipFree(p->opScratch);
     p->magic = 0;
     delete p;
     return TFQMRGPU_STATUS_SUCCESS;
@@ -680,6 +735,13 @@ tfqmrgpuStatus_t tfqmrgpuExt_commDestroy(tfqmrgpuHandle_t handle) {
     if (!h) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
     h->comm = nullptr; h->nranks = 1; h->rank = 0;
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+tfqmrgpuStatus_t tfqmrgpuExt_setOperator(tfqmrgpuBsrsvPlan_t plan, tfqmrgpuOperator_t multiply, void* ctx) {
+    auto p = asPlan(plan);
+    if (!p) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    p->opFn = (void*)multiply; p->opCtx = ctx;
     return TFQMRGPU_STATUS_SUCCESS;
 }
 

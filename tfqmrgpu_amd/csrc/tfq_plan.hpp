@@ -88,6 +88,10 @@ struct Plan {
     void* ringEvent[kDepth] = {};      // hipEvent_t behind each copy
     int shadowMode = TFQMRGPU_SHADOW_HASH;
     bool haveB = false;
+    // user-defined operator (tfqmrgpu_ext.h section 5): callback, and library-owned device scratch
+    // [xu | yu | i2u | colindx in the caller's block order]
+    void* opFn = nullptr; void* opCtx = nullptr;
+    char* opScratch = nullptr;
 
     // ---- results of the last solve -------------------------------------------------------------
     double residuum_reached = 0, flops_performed = -1, flops_performed_all = 0;

@@ -39,6 +39,7 @@ struct SpmmArgs {
     void* e0; void const* e1; void const* sc; float const* v3;
     void const* B; uint32_t const* bOfX;
     double* pz; double* pd;
+    void const* Yext; uint32_t const* yPerm;   // k_spmm_direct only: take block y of the product from Yext[yPerm[y]]
 };
 
 template <int EPI> struct EpiPlanes { static constexpr int N = (EPI == EPI_XPAY_DOT) ? 2 : (EPI == EPI_AXPY_NRM_DOT) ? 3 : (EPI == EPI_RESIDUAL) ? 1 : 0; };
@@ -154,6 +155,11 @@ __global__ __launch_bounds__(256) void k_spmm_direct(SpmmArgs a) {
         R yr[NACC], yi[NACC];
 #pragma unroll
         for (int n = 0; n < NACC; ++n) { yr[n] = 0; yi[n] = 0; }
+        if (a.Yext) {   // product computed by a user-defined operator
+            R const* Yb = (R const*)a.Yext + size_t(a.yPerm[y]) * 2 * P;
+#pragma unroll
+            for (int n = 0; n < NACC; ++n) { yr[n] = Yb[e0 + n * 256]; yi[n] = Yb[P + e0 + n * 256]; }
+        } else
         for (uint32_t q = a.starts[y]; q < a.starts[y + 1]; ++q) {
             R const* Ab = (R const*)a.A + size_t(a.pairs[2 * size_t(q)]) * 2 * LM * LM;
             R const* Xb = (R const*)a.X + size_t(a.pairs[2 * size_t(q) + 1]) * 2 * P;
@@ -520,7 +526,7 @@ static bool spmm_dispatch(bool dbl, int lm, int ln, int epi, SpmmArgs const& a, 
 #undef TFQ_CASE
 }
 
-void spmm_launch(int epi, DevPlan const& d, hipStream_t s) {
+static SpmmArgs spmm_args(int epi, DevPlan const& d) {
     SpmmArgs a{};
     a.A = d.A; a.starts = d.starts; a.pairs = d.pairs; a.nY = d.nnzbX;
     a.chunkFirst = d.chunkFirst; a.chunkCol = d.chunkCol; a.CH = 0;
@@ -531,9 +537,34 @@ void spmm_launch(int epi, DevPlan const& d, hipStream_t s) {
     case EPI_XPAY_DOT:     a.X = d.v6; a.Y = d.v9; a.e0 = d.v4; a.e1 = d.v8; a.sc = d.beta; a.gate = 1; break;
     case EPI_AXPY_NRM_DOT: a.X = d.v6; a.Y = d.v8; a.e0 = d.v5; a.sc = d.alfa; a.gate = 1; break;
     case EPI_RESIDUAL:     a.X = d.x;  a.Y = nullptr; a.gate = 2; break;
-    default: return;
+    default: break;
     }
-    spmm_dispatch(d.dbl, d.LM, d.LN, epi, a, d.nChunks, s);
+    return a;
+}
+
+void spmm_launch(int epi, DevPlan const& d, hipStream_t s) {
+    if (epi != EPI_XPAY_DOT && epi != EPI_AXPY_NRM_DOT && epi != EPI_RESIDUAL) return;
+    spmm_dispatch(d.dbl, d.LM, d.LN, epi, spmm_args(epi, d), d.nChunks, s);
+}
+
+template <typename R, int LM, int LN>
+static void epi_only(int epi, SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
+    if (0 == nWG) return;
+    switch (epi) {
+    case EPI_XPAY_DOT:     k_spmm_direct<R, LM, LN, EPI_XPAY_DOT><<<dim3(nWG), dim3(256), 0, s>>>(a); break;
+    case EPI_AXPY_NRM_DOT: k_spmm_direct<R, LM, LN, EPI_AXPY_NRM_DOT><<<dim3(nWG), dim3(256), 0, s>>>(a); break;
+    case EPI_RESIDUAL:     k_spmm_direct<R, LM, LN, EPI_RESIDUAL><<<dim3(nWG), dim3(256), 0, s>>>(a); break;
+    }
+}
+
+void epilogue_launch(int epi, DevPlan const& d, void const* Yext, uint32_t const* i2u, hipStream_t s) {
+    SpmmArgs a = spmm_args(epi, d);
+    a.order = nullptr; a.Yext = Yext; a.yPerm = i2u;
+    int const key = d.LM * 1000 + d.LN;
+#define TFQ_CASE(R, LM, LN) case LM * 1000 + LN: epi_only<R, LM, LN>(epi, a, d.nChunks, s); break;
+    if (d.dbl) { switch (key) { TFQ_SIZES(TFQ_CASE, double) default: break; } }
+    else       { switch (key) { TFQ_SIZES(TFQ_CASE, float)  default: break; } }
+#undef TFQ_CASE
 }
 
 tfqmrgpuStatus_t launch_multiply(char precision, int lm, int ln, uint32_t nnzbY,
