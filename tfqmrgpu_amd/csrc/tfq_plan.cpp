@@ -232,7 +232,9 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     {
         size_t const blockBytes = blockElems * p.realBytes;
         size_t target = p.S / 4096;
-        target = std::min<size_t>(std::max<size_t>(target, 8 * 1024), 64 * 1024);
+        size_t maxKiB = 64;
+        if (auto v = std::getenv("TFQMRGPU_CHUNK_KIB")) maxKiB = std::max(8, std::atoi(v));
+        target = std::min<size_t>(std::max<size_t>(target, 8 * 1024), maxKiB * 1024);
         uint32_t const CH = uint32_t(std::max<size_t>(1, target / blockBytes));
         auto& c = p.chunks;
         c.first.clear(); c.col.clear(); c.colPtr.assign(size_t(p.nCols) + 1, 0);
