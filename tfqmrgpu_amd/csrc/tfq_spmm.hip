@@ -11,9 +11,10 @@
 //  * k_spmm_mfma : LM and LN multiples of 16.  One wavefront owns a 16 x LN strip of one Y block
 //    and keeps it in MFMA accumulators (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32).  The
 //    native layouts ARE the MFMA operand layouts: lane l feeds A[k0 + l/16][i0 + l%16] and
-//    X[k0 + l/16][j0 + l%16], i.e. four consecutive 128-byte rows per load instruction, so operands go
-//    global -> VGPR fully coalesced with no LDS transpose.  4 real MFMA chains per complex product
-//    (-Im(A) is formed once per operand).
+//    X[k0 + l/16][columns of lane l%16], i.e. four consecutive rows per load instruction, so operands go
+//    global -> VGPR fully coalesced with no LDS transpose.  With several 16-column tiles per strip a lane
+//    owns NEIGHBOURING columns (ColMap below) and moves them as one 16-byte access.  4 real MFMA chains
+//    per complex product (-Im(A) is formed once per operand).
 //  * k_spmm_mfma8 : LM == 8, LN multiple of 8: [Re A; Im A] x [Re X | Im X] fills one 16 x 16 tile.
 //  * k_spmm_direct : every other block shape (LM == 4, LN in {9, 10}); one thread per output element,
 //    operands through the vector L1.
@@ -83,31 +84,6 @@ __device__ inline void epilogue(SpmmArgs const& a, size_t off, int P, R yr, R yi
         }
         double const dr = rr, di = ri;
         acc[0] += dr * dr + di * di;
-    }
-}
-
-// the same with the epilogue operands already in registers (ur,ui: old v4|v5, xr,xi: v8, wr,wi: v3)
-template <typename R, int EPI>
-__device__ inline void epilogue_pre(SpmmArgs const& a, size_t off, int P, R yr, R yi, R sr, R si,
-                                    R ur, R ui, R xr, R xi, float wrf, float wif, double* acc)
-{
-    ((R*)a.Y)[off] = yr; ((R*)a.Y)[off + P] = yi;
-    R* e0 = (R*)a.e0;
-    double const wr = wrf, wi = wif;
-    if constexpr (EPI == EPI_XPAY_DOT) {
-        R tr = xr + sr * ur - si * ui, ti = xi + si * ur + sr * ui;
-        ur = yr + sr * tr - si * ti; ui = yi + si * tr + sr * ti;
-        e0[off] = ur; e0[off + P] = ui;
-        double const dr = ur, di = ui;
-        acc[0] += dr * wr - di * wi;
-        acc[1] += dr * wi + di * wr;
-    } else {
-        R const nr = sr * yr - si * yi + ur, ni = si * yr + sr * yi + ui;
-        e0[off] = nr; e0[off + P] = ni;
-        double const dr = nr, di = ni;
-        acc[0] += dr * wr - di * wi;
-        acc[1] += dr * wi + di * wr;
-        acc[2] += dr * dr + di * di;
     }
 }
 
@@ -221,19 +197,59 @@ template <> struct Acc<float> {
     __device__ static inline int row(int lane, int r) { return 4 * (lane >> 4) + r; }
 };
 
+// NT consecutive elements as one access (NT * sizeof(R) bytes, naturally aligned by construction)
+template <typename R, int N> struct VecOf { using T = R __attribute__((ext_vector_type(N))); };
+template <typename R, int N>
+__device__ inline void vload(R (&dst)[N], R const* p) {
+    if constexpr (N == 1) dst[0] = *p;
+    else {
+        auto const v = *reinterpret_cast<typename VecOf<R, N>::T const*>(p);
+#pragma unroll
+        for (int i = 0; i < N; ++i) dst[i] = v[i];
+    }
+}
+template <typename R, int N>
+__device__ inline void vstore(R* p, R const (&src)[N]) {
+    if constexpr (N == 1) *p = src[0];
+    else {
+        typename VecOf<R, N>::T v;
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = src[i];
+        *reinterpret_cast<typename VecOf<R, N>::T*>(p) = v;
+    }
+}
+
+// Column map of the MFMA kernel: a lane touches NT block columns (one per accumulator tile).  They are chosen as
+// NT/VW groups of VW NEIGHBOURS, VW * sizeof(R) = 16 bytes where NT allows: tile nt of lane column lc holds block
+// column (nt/VW) * 16 VW + lc * VW + nt % VW (not nt * 16 + lc).  X operands and every epilogue vector then move
+// as 16-byte accesses, 256 contiguous bytes per row and lane group (the memory pipe retires one wave-wide access
+// per 16 clocks whatever its width, scripts/ta_rate.hip).  Which 16 columns share a tile is free.
+template <typename R, int NT> struct ColMap {
+    static constexpr int VW = (NT * sizeof(R) <= 16) ? NT : int(16 / sizeof(R));   // columns per access
+    static constexpr int NG = NT / VW;                                             // accesses per row
+    __device__ static inline int col(int lc, int nt) { return (nt / VW) * 16 * VW + lc * VW + nt % VW; }
+};
+
 // operands of one "slice" = KSL consecutive MFMA k-steps (4 k each) of one block product
 template <typename R, int NT, int KSL>
 struct Slice {
     R ar[KSL], ai[KSL], xr[KSL][NT], xi[KSL][NT];
+    // Ab: A block + row of this lane, Xb: X block + first column of this lane (lc * VW)
     template <int LM, int LN>
     __device__ inline void load(R const* __restrict__ Ab, R const* __restrict__ Xb, int k0, int lr) {
-        constexpr int P = LM * LN;
+        constexpr int P = LM * LN, VW = ColMap<R, NT>::VW, NG = ColMap<R, NT>::NG;
 #pragma unroll
         for (int s = 0; s < KSL; ++s) {
             int const k = k0 + 4 * s + lr;
             ar[s] = Ab[k * LM]; ai[s] = Ab[LM * LM + k * LM];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) { xr[s][nt] = Xb[k * LN + nt * 16]; xi[s][nt] = Xb[P + k * LN + nt * 16]; }
+            for (int g = 0; g < NG; ++g) {
+                R vr[VW], vi[VW];
+                vload<R, VW>(vr, Xb + k * LN + g * 16 * VW);
+                vload<R, VW>(vi, Xb + P + k * LN + g * 16 * VW);
+#pragma unroll
+                for (int n = 0; n < VW; ++n) { xr[s][g * VW + n] = vr[n]; xi[s][g * VW + n] = vi[n]; }
+            }
         }
     }
     template <typename T4>
@@ -252,6 +268,60 @@ struct Slice {
     }
 };
 
+// the vectors an epilogue reads, for the NT neighbouring elements of one lane in one row
+template <typename R, int EPI, int NT>
+struct EpiOps {
+    R ur[NT], ui[NT], xr[NT], xi[NT];
+    float wr[NT], wi[NT];
+    __device__ inline void load(SpmmArgs const& a, size_t off, int P) {
+        if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
+            vload<R, NT>(ur, (R const*)a.e0 + off); vload<R, NT>(ui, (R const*)a.e0 + off + P);
+            vload<float, NT>(wr, a.v3 + off); vload<float, NT>(wi, a.v3 + off + P);
+        }
+        if constexpr (EPI == EPI_XPAY_DOT) { vload<R, NT>(xr, (R const*)a.e1 + off); vload<R, NT>(xi, (R const*)a.e1 + off + P); }
+    }
+};
+
+// epilogue for VW neighbouring elements at `off` (same arithmetic per element as epilogue<> above); the elements
+// are columns n0 .. n0 + VW - 1 of the NT columns of the lane (per-RHS scalars sr/si and partial sums are per column)
+template <typename R, int EPI, int VW, int NPL, int NT>
+__device__ inline void epilogue_row(SpmmArgs const& a, size_t off, int P, R const (&yr)[VW], R const (&yi)[VW],
+                                    R const (&sr)[NT], R const (&si)[NT], int n0, EpiOps<R, EPI, VW> const& o,
+                                    uint32_t bq, int eoff, double (&part)[NPL > 0 ? NPL : 1][NT])
+{
+    if constexpr (EPI != EPI_RESIDUAL) { vstore<R, VW>((R*)a.Y + off, yr); vstore<R, VW>((R*)a.Y + off + P, yi); }
+    if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
+        R nr[VW], ni[VW];
+#pragma unroll
+        for (int n = 0; n < VW; ++n) {
+            R const cr = sr[n0 + n], ci = si[n0 + n];
+            if constexpr (EPI == EPI_XPAY_DOT) {
+                R const tr = o.xr[n] + cr * o.ur[n] - ci * o.ui[n], ti = o.xi[n] + ci * o.ur[n] + cr * o.ui[n];
+                nr[n] = yr[n] + cr * tr - ci * ti; ni[n] = yi[n] + ci * tr + cr * ti;
+            } else {
+                nr[n] = cr * yr[n] - ci * yi[n] + o.ur[n]; ni[n] = ci * yr[n] + cr * yi[n] + o.ui[n];
+            }
+            double const wr = o.wr[n], wi = o.wi[n], dr = nr[n], di = ni[n];
+            part[0][n0 + n] += dr * wr - di * wi;
+            part[1][n0 + n] += dr * wi + di * wr;
+            if constexpr (EPI == EPI_AXPY_NRM_DOT) part[2][n0 + n] += dr * dr + di * di;
+        }
+        vstore<R, VW>((R*)a.e0 + off, nr); vstore<R, VW>((R*)a.e0 + off + P, ni);
+    } else if constexpr (EPI == EPI_RESIDUAL) {
+        R br[VW] = {}, bi[VW] = {};
+        if (bq != 0xffffffffu) {
+            R const* b = (R const*)a.B + size_t(bq) * 2 * P;
+            vload<R, VW>(br, b + eoff); vload<R, VW>(bi, b + eoff + P);
+        }
+#pragma unroll
+        for (int n = 0; n < VW; ++n) {
+            R const rr = yr[n] + R(-1) * br[n], ri = yi[n] + R(-1) * bi[n];
+            double const dr = rr, di = ri;
+            part[0][n0 + n] += dr * dr + di * di;
+        }
+    }
+}
+
 template <typename R, int LM, int LN, int EPI, bool PRE>
 __global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
     if (gate_closed(a)) return;
@@ -260,10 +330,12 @@ __global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
     constexpr int KSL = (NT >= 4) ? 2 : 4;           // k-steps per slice: bounds the registers of the prefetch
     constexpr int SPP = LM / (4 * KSL);              // slices per block product
     constexpr int NPL = EpiPlanes<EPI>::N;
+    constexpr int VW = ColMap<R, NT>::VW, NG = ColMap<R, NT>::NG;
     using T4 = typename Acc<R>::T;
     int const lane = threadIdx.x & 63;
     int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int const lr = lane >> 4, lc = lane & 15;
+    int const c0 = lc * VW;                          // first block column of this lane, further groups 16 VW apart
     // work groups that are dispatched to the same XCD (blockIdx % 8, observed round-robin) get neighbouring
     // chunks (a.order, tfq_plan.cpp), so that the A blocks shared by neighbouring block columns are served
     // by that XCD's L2
@@ -278,8 +350,8 @@ __global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
     if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            sr[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + nt * 16 + lc];
-            si[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + nt * 16 + lc];
+            sr[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + ColMap<R, NT>::col(lc, nt)];
+            si[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + ColMap<R, NT>::col(lc, nt)];
         }
     }
     double part[NPL > 0 ? NPL : 1][NT] = {};
@@ -294,7 +366,7 @@ __global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
         uint32_t const q0 = a.starts[y];
         uint32_t const nT = (a.starts[y + 1] - q0) * SPP;   // slices of this strip
         R const* const A0 = (R const*)a.A + i0 + lc;
-        R const* const X0 = (R const*)a.X + lc;
+        R const* const X0 = (R const*)a.X + c0;
         auto fetch = [&](Slice<R, NT, KSL>& o, uint32_t t) {
             uint32_t const q = q0 + t / SPP;
             int const k0 = int(t % SPP) * (4 * KSL);
@@ -308,20 +380,13 @@ __global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
         Slice<R, NT, KSL> o0, o1;
         if (nT > 0) fetch(o0, 0);
         if (nT > 1) fetch(o1, 1);
-        constexpr int NE = PRE ? NT : 1, N4 = PRE ? 4 : 1;
-        R pur[NE][N4], pui[NE][N4], pxr[NE][N4], pxi[NE][N4];
-        float pwr[NE][N4], pwi[NE][N4];
+        EpiOps<R, EPI, VW> ops[PRE ? 4 * NG : 1];
         if constexpr (PRE) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    size_t const off = size_t(y) * 2 * P + (i0 + Acc<R>::row(lane, r)) * LN + nt * 16 + lc;
-                    pur[nt][r] = ((R const*)a.e0)[off]; pui[nt][r] = ((R const*)a.e0)[off + P];
-                    if constexpr (EPI == EPI_XPAY_DOT) { pxr[nt][r] = ((R const*)a.e1)[off]; pxi[nt][r] = ((R const*)a.e1)[off + P]; }
-                    else { pxr[nt][r] = 0; pxi[nt][r] = 0; }
-                    pwr[nt][r] = a.v3[off]; pwi[nt][r] = a.v3[off + P];
-                }
+                for (int g = 0; g < NG; ++g)
+                    ops[r * NG + g].load(a, size_t(y) * 2 * P + (i0 + Acc<R>::row(lane, r)) * LN + c0 + g * 16 * VW, P);
         }
         uint32_t t = 0;
         for (; t + 2 <= nT; t += 2) {
@@ -335,16 +400,16 @@ __global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
         uint32_t bq = 0xffffffffu;
         if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int const e = (i0 + Acc<R>::row(lane, r)) * LN + nt * 16 + lc;
-                double acc[NPL > 0 ? NPL : 1] = {};
-                if constexpr (PRE) epilogue_pre<R, EPI>(a, size_t(y) * 2 * P + e, P, cre[nt][r], cim[nt][r], sr[nt], si[nt],
-                                                        pur[nt][r], pui[nt][r], pxr[nt][r], pxi[nt][r], pwr[nt][r], pwi[nt][r], acc);
-                else epilogue<R, EPI>(a, size_t(y) * 2 * P + e, P, cre[nt][r], cim[nt][r], sr[nt], si[nt], bq, e, acc);
+            for (int g = 0; g < NG; ++g) {           // accesses of at most 16 bytes per lane
+                int const e = (i0 + Acc<R>::row(lane, r)) * LN + c0 + g * 16 * VW;
+                size_t const off = size_t(y) * 2 * P + e;
+                R yr[VW], yi[VW];
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) part[p][nt] += acc[p];
+                for (int n = 0; n < VW; ++n) { yr[n] = cre[g * VW + n][r]; yi[n] = cim[g * VW + n][r]; }
+                if constexpr (!PRE) ops[0].load(a, off, P);
+                epilogue_row<R, EPI, VW, NPL, NT>(a, off, P, yr, yi, sr, si, g * VW, ops[PRE ? r * NG + g : 0], bq, e, part);
             }
         }
     }
@@ -359,7 +424,7 @@ __global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
                 double v = part[p][nt];
                 v += __shfl_xor(v, 16);
                 v += __shfl_xor(v, 32);
-                if (lane < 16) s[wave][p][nt * 16 + lane] = v;
+                if (lane < 16) s[wave][p][ColMap<R, NT>::col(lane, nt)] = v;
             }
         __syncthreads();
         for (int e = threadIdx.x; e < NPL * LN; e += 256) {
