@@ -235,7 +235,14 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
         size_t maxKiB = 64;
         if (auto v = std::getenv("TFQMRGPU_CHUNK_KIB")) maxKiB = std::max(8, std::atoi(v));
         target = std::min<size_t>(std::max<size_t>(target, 8 * 1024), maxKiB * 1024);
-        uint32_t const CH = uint32_t(std::max<size_t>(1, target / blockBytes));
+        uint32_t CH = uint32_t(std::max<size_t>(1, target / blockBytes));
+        // every wave of a work group wants a unit of work: the MFMA multiply cuts a block into strips of 16 or
+        // 32 rows (RowTiles in tfq_spmm.hip), one strip per wave and pass
+        if (LM % 16 == 0 && LN % 16 == 0) {
+            int const mt = LM / 16, ms = (mt % 2 == 0 && 2 * (LN / 16) * p.realBytes <= 32) ? 2 : 1;
+            uint32_t const perBlock = uint32_t(mt / ms);
+            CH = std::max(CH, (4 + perBlock - 1) / perBlock);
+        }
         auto& c = p.chunks;
         c.first.clear(); c.col.clear(); c.colPtr.assign(size_t(p.nCols) + 1, 0);
         std::vector<uint32_t> bandOf;                        // band of CH block rows in which a chunk starts

@@ -230,18 +230,25 @@ template <typename R, int NT> struct ColMap {
     __device__ static inline int col(int lc, int nt) { return (nt / VW) * 16 * VW + lc * VW + nt % VW; }
 };
 
-// operands of one "slice" = KSL consecutive MFMA k-steps (4 k each) of one block product
-template <typename R, int NT, int KSL>
+// row tiles per wave: two where the block has them and the accumulators (MS * NT complex tiles) stay within 64 VGPRs
+template <typename R, int MT, int NT> struct RowTiles {
+    static constexpr int MS = (MT % 2 == 0 && 2 * NT * sizeof(R) <= 32) ? 2 : 1;
+};
+
+// operands of one "slice" = KSL consecutive MFMA k-steps (4 k each) of one block product, for a strip of
+// MS * 16 block rows: the wave owns MS row tiles, tile ms of lane column lc holds block row i0 + lc * MS + ms, so
+// that the A operand too moves as one MS-wide access and every X operand feeds MS tiles
+template <typename R, int MS, int NT, int KSL>
 struct Slice {
-    R ar[KSL], ai[KSL], xr[KSL][NT], xi[KSL][NT];
-    // Ab: A block + row of this lane, Xb: X block + first column of this lane (lc * VW)
+    R ar[KSL][MS], ai[KSL][MS], xr[KSL][NT], xi[KSL][NT];
+    // Ab: A block + first row of this lane (i0 + lc * MS), Xb: X block + first column of this lane (lc * VW)
     template <int LM, int LN>
     __device__ inline void load(R const* __restrict__ Ab, R const* __restrict__ Xb, int k0, int lr) {
         constexpr int P = LM * LN, VW = ColMap<R, NT>::VW, NG = ColMap<R, NT>::NG;
 #pragma unroll
         for (int s = 0; s < KSL; ++s) {
             int const k = k0 + 4 * s + lr;
-            ar[s] = Ab[k * LM]; ai[s] = Ab[LM * LM + k * LM];
+            vload<R, MS>(ar[s], Ab + k * LM); vload<R, MS>(ai[s], Ab + LM * LM + k * LM);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 R vr[VW], vi[VW];
@@ -253,18 +260,20 @@ struct Slice {
         }
     }
     template <typename T4>
-    __device__ inline void mma(T4 (&cre)[NT], T4 (&cim)[NT]) const {
+    __device__ inline void mma(T4 (&cre)[MS][NT], T4 (&cim)[MS][NT]) const {
 #pragma unroll
-        for (int s = 0; s < KSL; ++s) {
-            R const nai = -ai[s];
+        for (int s = 0; s < KSL; ++s)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                cre[nt] = Acc<R>::mma(ar[s], xr[s][nt], cre[nt]);
-                cim[nt] = Acc<R>::mma(ar[s], xi[s][nt], cim[nt]);
-                cre[nt] = Acc<R>::mma(nai, xi[s][nt], cre[nt]);
-                cim[nt] = Acc<R>::mma(ai[s], xr[s][nt], cim[nt]);
+            for (int ms = 0; ms < MS; ++ms) {
+                R const nai = -ai[s][ms];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    cre[ms][nt] = Acc<R>::mma(ar[s][ms], xr[s][nt], cre[ms][nt]);
+                    cim[ms][nt] = Acc<R>::mma(ar[s][ms], xi[s][nt], cim[ms][nt]);
+                    cre[ms][nt] = Acc<R>::mma(nai, xi[s][nt], cre[ms][nt]);
+                    cim[ms][nt] = Acc<R>::mma(ai[s][ms], xr[s][nt], cim[ms][nt]);
+                }
             }
-        }
     }
 };
 
@@ -323,11 +332,13 @@ __device__ inline void epilogue_row(SpmmArgs const& a, size_t off, int P, R cons
 }
 
 template <typename R, int LM, int LN, int EPI, bool PRE>
-__global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
+__global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at least 2 waves per SIMD: 256 VGPRs at most
     if (gate_closed(a)) return;
     static_assert(LM % 16 == 0 && LN % 16 == 0, "MFMA tiles are 16 x 16");
     constexpr int P = LM * LN, MT = LM / 16, NT = LN / 16;
-    constexpr int KSL = (NT >= 4) ? 2 : 4;           // k-steps per slice: bounds the registers of the prefetch
+    constexpr int MS = RowTiles<R, MT, NT>::MS;      // row tiles per wave
+    constexpr int MU = MT / MS;                      // strips per Y block
+    constexpr int KSL = (MS * NT >= 4) ? 2 : 4;      // k-steps per slice: bounds the registers of the prefetch
     constexpr int SPP = LM / (4 * KSL);              // slices per block product
     constexpr int NPL = EpiPlanes<EPI>::N;
     constexpr int VW = ColMap<R, NT>::VW, NG = ColMap<R, NT>::NG;
@@ -356,37 +367,43 @@ __global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
     }
     double part[NPL > 0 ? NPL : 1][NT] = {};
 
-    uint32_t const nUnits = (last - first) * MT;     // unit = 16-row strip of one Y block
+    uint32_t const nUnits = (last - first) * MU;     // unit = strip of MS * 16 rows of one Y block
     for (uint32_t u = wave; u < nUnits; u += 4) {
-        uint32_t const y = first + u / MT;
-        int const i0 = int(u % MT) * 16;
-        T4 cre[NT], cim[NT];
+        uint32_t const y = first + u / MU;
+        int const i0 = int(u % MU) * 16 * MS;
+        T4 cre[MS][NT], cim[MS][NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { cre[nt] = T4{0, 0, 0, 0}; cim[nt] = T4{0, 0, 0, 0}; }
+        for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { cre[ms][nt] = T4{0, 0, 0, 0}; cim[ms][nt] = T4{0, 0, 0, 0}; }
         uint32_t const q0 = a.starts[y];
         uint32_t const nT = (a.starts[y + 1] - q0) * SPP;   // slices of this strip
-        R const* const A0 = (R const*)a.A + i0 + lc;
+        R const* const A0 = (R const*)a.A + i0 + lc * MS;
         R const* const X0 = (R const*)a.X + c0;
-        auto fetch = [&](Slice<R, NT, KSL>& o, uint32_t t) {
+        auto fetch = [&](Slice<R, MS, NT, KSL>& o, uint32_t t) {
             uint32_t const q = q0 + t / SPP;
             int const k0 = int(t % SPP) * (4 * KSL);
             o.template load<LM, LN>(A0 + size_t(a.pairs[2 * size_t(q)]) * 2 * LM * LM,
                                     X0 + size_t(a.pairs[2 * size_t(q) + 1]) * 2 * P, k0, lr);
         };
+        // block row of accumulator register r of row tile ms
+        auto row_of = [&](int ms, int r) { return i0 + Acc<R>::row(lane, r) * MS + ms; };
         // software pipeline, two register sets: the loads of slices t+1, t+2 are in flight while the MFMAs
         // of slice t issue.  With PRE the operands of the epilogue (old v4|v5, v8, v3) are requested right
         // behind the first two slices: vmcnt retires in order, so they must be younger than the slices
         // whose MFMAs should start first and they have two slices of matrix work to arrive.
-        Slice<R, NT, KSL> o0, o1;
+        Slice<R, MS, NT, KSL> o0, o1;
         if (nT > 0) fetch(o0, 0);
         if (nT > 1) fetch(o1, 1);
-        EpiOps<R, EPI, VW> ops[PRE ? 4 * NG : 1];
+        EpiOps<R, EPI, VW> ops[PRE ? MS * 4 * NG : 1];
         if constexpr (PRE) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-                for (int g = 0; g < NG; ++g)
-                    ops[r * NG + g].load(a, size_t(y) * 2 * P + (i0 + Acc<R>::row(lane, r)) * LN + c0 + g * 16 * VW, P);
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        ops[(ms * 4 + r) * NG + g].load(a, size_t(y) * 2 * P + row_of(ms, r) * LN + c0 + g * 16 * VW, P);
         }
         uint32_t t = 0;
         for (; t + 2 <= nT; t += 2) {
@@ -400,18 +417,19 @@ __global__ __launch_bounds__(256) void k_spmm_mfma(SpmmArgs a) {
         uint32_t bq = 0xffffffffu;
         if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {           // accesses of at most 16 bytes per lane
-                int const e = (i0 + Acc<R>::row(lane, r)) * LN + c0 + g * 16 * VW;
-                size_t const off = size_t(y) * 2 * P + e;
-                R yr[VW], yi[VW];
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int n = 0; n < VW; ++n) { yr[n] = cre[g * VW + n][r]; yi[n] = cim[g * VW + n][r]; }
-                if constexpr (!PRE) ops[0].load(a, off, P);
-                epilogue_row<R, EPI, VW, NPL, NT>(a, off, P, yr, yi, sr, si, g * VW, ops[PRE ? r * NG + g : 0], bq, e, part);
-            }
-        }
+                for (int g = 0; g < NG; ++g) {       // accesses of at most 16 bytes per lane
+                    int const e = row_of(ms, r) * LN + c0 + g * 16 * VW;
+                    size_t const off = size_t(y) * 2 * P + e;
+                    R yr[VW], yi[VW];
+#pragma unroll
+                    for (int n = 0; n < VW; ++n) { yr[n] = cre[ms][g * VW + n][r]; yi[n] = cim[ms][g * VW + n][r]; }
+                    if constexpr (!PRE) ops[0].load(a, off, P);
+                    epilogue_row<R, EPI, VW, NPL, NT>(a, off, P, yr, yi, sr, si, g * VW, ops[PRE ? (ms * 4 + r) * NG + g : 0], bq, e, part);
+                }
     }
 
     if constexpr (NPL > 0) {
@@ -642,7 +660,9 @@ tfqmrgpuStatus_t launch_multiply(char precision, int lm, int ln, uint32_t nnzbY,
     // plain mode: enough work groups to fill 256 CUs several times, at least one strip per wave
     bool const mfma = (lm % 16 == 0 && ln % 16 == 0);
     int const mt = mfma ? lm / 16 : 1;
-    uint32_t ch = (mt >= 4) ? 1 : 4 / mt;                 // one 16-row strip per wave
+    int const ms = (mt % 2 == 0 && 2 * (ln / 16) * (dbl ? 8 : 4) <= 32) ? 2 : 1;   // RowTiles<>::MS
+    int const mu = mt / ms;                               // strips per Y block
+    uint32_t ch = (mu >= 4) ? 1 : 4 / mu;                 // one strip per wave
     if (!mfma) ch = (lm * ln >= 256) ? 1 : 256 / (lm * ln); // one Y block per thread group
     if (8 == lm && ln % 8 == 0) ch = 4;                     // k_spmm_mfma8: one Y block per wave
     a.CH = ch;
