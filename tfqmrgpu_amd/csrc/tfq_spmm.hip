@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_spmm_direct(SpmmArgs a) {
     int const g = (P >= 256) ? 0 : t / P;
     int const e0 = (P >= 256) ? t : t % P;
     bool const active = (g < GRP);
-    uint32_t const chunk = blockIdx.x;
+    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;   // XCD-aware launch order (tfq_plan.cpp)
     uint32_t first, last, col = 0;
     if (a.chunkFirst) { first = a.chunkFirst[chunk]; last = a.chunkFirst[chunk + 1]; col = a.chunkCol[chunk]; }
     else { first = chunk * a.CH; last = min(first + a.CH, a.nY); }
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
     int const lr = lane >> 4, lc = lane & 15;
     int const part8 = lc >> 3, j8 = lc & 7;            // operand side: plane and column inside the tile
     int const ei = lane >> 3, ej = lane & 7;           // epilogue side: element (ei, ej) of the 8 x 8 tile
-    uint32_t const chunk = blockIdx.x;
+    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;   // XCD-aware launch order (tfq_plan.cpp)
     uint32_t first, last, col = 0;
     if (a.chunkFirst) { first = a.chunkFirst[chunk]; last = a.chunkFirst[chunk + 1]; col = a.chunkCol[chunk]; }
     else { first = chunk * a.CH; last = min(first + a.CH, a.nY); }
@@ -613,8 +613,7 @@ static SpmmArgs spmm_args(int epi, DevPlan const& d) {
     SpmmArgs a{};
     a.A = d.A; a.starts = d.starts; a.pairs = d.pairs; a.nY = d.nnzbX;
     a.chunkFirst = d.chunkFirst; a.chunkCol = d.chunkCol; a.CH = 0;
-    bool const mfma = (d.LM % 16 == 0 && d.LN % 16 == 0);
-    a.order = mfma ? d.order : nullptr;
+    a.order = d.order;
     a.ctl = d.ctl; a.v3 = d.v3; a.B = d.B; a.bOfX = d.bOfX; a.pz = d.pz; a.pd = d.pd;
     switch (epi) {
     case EPI_XPAY_DOT:     a.X = d.v6; a.Y = d.v9; a.e0 = d.v4; a.e1 = d.v8; a.sc = d.beta; a.gate = 1; break;
