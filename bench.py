@@ -152,7 +152,23 @@ def main():
             t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device="cuda")
             dist.broadcast(t, 0)
             uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
-            T._check(T.lib.tfqmrgpuExt_commInit(s.handle, world, rank, uid), "tfqmrgpuExt_commInit")
+            ok = torch.tensor([1 if T.lib.tfqmrgpuExt_commInit(s.handle, world, rank, uid) == 0 else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            reduce_path = "rccl (library's own communicator on the solver stream)"
+            if int(ok.item()) == 0:
+                # the library could not set up its own communicator on every rank: same protocol through the host
+                # callback, reduced with torch.distributed (slower: one host round trip per stopping test)
+                T.lib.tfqmrgpuExt_commDestroy(s.handle)
+                reduce_path = "host callback over torch.distributed"
+
+                def reduce_max(ctx, values, n):
+                    v = torch.tensor([values[i] for i in range(n)], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(v, op=dist.ReduceOp.MAX)
+                    v = v.cpu()
+                    for i in range(n):
+                        values[i] = float(v[i])
+                keep_cb = T.REDUCE_CB(reduce_max)
+                T._check(T.lib.tfqmrgpuExt_setReduceCallback(s.handle, keep_cb, None), "tfqmrgpuExt_setReduceCallback")
 
         def barrier():
             torch.cuda.synchronize()
@@ -247,7 +263,8 @@ def main():
                 "dtype": "f64" if prec == "z" else "f32", "data": "synthetic",
                 "config": {"workload": desc, "name": args.workload, "mb": pr.mb, "nnzbA": pr.nnzbA, "nnzbX_per_gpu": pr.nnzbX,
                            "block_columns_per_gpu": view["nCols"], "rhs_per_gpu": view["nCols"] * pr.LN, "pairs": nPairs,
-                           "threshold": pr.tolerance, "sharding": "block columns of X/B per GPU, RCCL max-all-reduce of the stopping test"},
+                           "threshold": pr.tolerance, "sharding": "block columns of X/B per GPU, max-all-reduce of the stopping test",
+                           "reduce_path": reduce_path if distributed else "none (one rank)"},
                 "iterations_per_solve": iters / args.steps,
                 "iterations_per_second": round(iters_all / world / elapsed, 2),
                 "rhs_iterations_per_second": round(iters_all * view["nCols"] * pr.LN / elapsed, 1),

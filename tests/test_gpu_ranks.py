@@ -1,0 +1,52 @@
+"""Multi-rank path of the PRODUCT on the GPU box: 2 and 3 ranks share cuda:0, block columns sharded with
+tfqmrgpuExt_shardColumns, stopping test max-reduced over ranks through the host callback (gloo).  The sharded run
+must take the iterations of the single-rank run and return bit-identical solution blocks:
+columns are independent systems, the default shadow vector is a hash of (column, row, element), every reduction is
+in a fixed order.  At most 4 processes touch the GPU.  Run with `pytest -m gpu`."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import tfqmrgpu_amd as T
+from conftest import ROOT, load_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,name,prec,tol", [(2, "fd_16x16_small", "z", 1e-9), (3, "stencil_8x8", "z", 1e-9),
+                                                 (2, "fd_16x16_2d", "c", 1e-4)])
+def test_ranks_sharing_one_gpu(tmp_path, world, name, prec, tol):
+    out = str(tmp_path / "sharded.npz")
+    env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "_gpu_rank_worker.py"), out, name, prec, repr(tol)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    g = np.load(out)
+    pr = load_problem(name)
+    with T.Solver() as s:                       # single rank, same settings
+        s.create_plan(pr)
+        s.set_buffer(nbytes=s.buffer_size(pr.LM, pr.LN, prec))
+        s.set_matrix("A", pr.A)
+        s.set_matrix("B", pr.B)
+        st = s.solve(tol, 300)
+        info, X, hist = s.get_info(), s.get_matrix(), s.bound_history()
+    assert st == 0 and list(g["status"]) == [0] * world
+    assert list(g["iterations"]) == [info["iterations"]] * world      # same decisions on every rank
+    assert sum(g["n_cols"]) == len(np.unique(pr.colIndX)) and min(g["n_cols"]) >= 1
+    for h in g["history"]:                                            # the reduced bound is the global one
+        assert np.array_equal(h, hist)
+    assert max(g["residual"]) == info["residual"]
+    assert np.array_equal(g["X"], X)                                  # bit-identical solution blocks
+    assert min(g["calls"]) >= info["iterations"]
