@@ -43,36 +43,43 @@ struct SpmmArgs {
     void const* Yext; uint32_t const* yPerm;   // k_spmm_direct only: take block y of the product from Yext[yPerm[y]]
 };
 
+// data that a kernel touches once (epilogue vectors) moves non-temporally, so that the stream does not push the A and
+// X blocks, which neighbouring work groups re-use, out of the L2 (measured on P2: fused multiply 0.825 -> 0.777 ms)
+// Only where a wave's access covers runs of at least 64 bytes: 32-byte runs (the 8-column tiles of k_spmm_mfma8 in
+// float) as non-temporal partial writes cost 2x (8x32 `c`: 1.27 -> 2.79 ms), so STREAM is a template switch.
+template <bool STREAM, typename T> __device__ inline T ld_stream(T const* p) { if constexpr (STREAM) return __builtin_nontemporal_load(p); else return *p; }
+template <bool STREAM, typename T> __device__ inline void st_stream(T* p, T v) { if constexpr (STREAM) __builtin_nontemporal_store(v, p); else *p = v; }
+
 template <int EPI> struct EpiPlanes { static constexpr int N = (EPI == EPI_XPAY_DOT) ? 2 : (EPI == EPI_AXPY_NRM_DOT) ? 3 : (EPI == EPI_RESIDUAL) ? 1 : 0; };
 
 // per-element epilogue; off = offset of the element's real part in an X-shaped vector, P = plane size
-template <typename R, int EPI>
+template <typename R, int EPI, bool STREAM = true>
 __device__ inline void epilogue(SpmmArgs const& a, size_t off, int P, R yr, R yi, R sr, R si,
                                 uint32_t bq, int eoff, double* acc /* [planes] */)
 {
     if constexpr (EPI == EPI_NONE) {
-        ((R*)a.Y)[off] = yr; ((R*)a.Y)[off + P] = yi;
+        st_stream<STREAM>((R*)a.Y + off, yr); st_stream<STREAM>((R*)a.Y + off + P, yi);
     } else if constexpr (EPI == EPI_XPAY_DOT) {
         // v9 := A v6 (kept for the v5 update); v4 := v8 + beta v4; v4 := v9 + beta v4; pz += v3 . v4
         // (tfqmrgpu_core.hxx:196-202)
-        ((R*)a.Y)[off] = yr; ((R*)a.Y)[off + P] = yi;
+        st_stream<STREAM>((R*)a.Y + off, yr); st_stream<STREAM>((R*)a.Y + off + P, yi);
         R* v4 = (R*)a.e0; R const* v8 = (R const*)a.e1;
-        R ur = v4[off], ui = v4[off + P];
-        R const xr = v8[off], xi = v8[off + P];
+        R ur = ld_stream<STREAM>(v4 + off), ui = ld_stream<STREAM>(v4 + off + P);
+        R const xr = ld_stream<STREAM>(v8 + off), xi = ld_stream<STREAM>(v8 + off + P);
         R tr = xr + sr * ur - si * ui, ti = xi + si * ur + sr * ui;
         ur = yr + sr * tr - si * ti; ui = yi + si * tr + sr * ti;
-        v4[off] = ur; v4[off + P] = ui;
-        double const wr = a.v3[off], wi = a.v3[off + P], dr = ur, di = ui;
+        st_stream<STREAM>(v4 + off, ur); st_stream<STREAM>(v4 + off + P, ui);
+        double const wr = ld_stream<STREAM>(a.v3 + off), wi = ld_stream<STREAM>(a.v3 + off + P), dr = ur, di = ui;
         acc[0] += dr * wr - di * wi;
         acc[1] += dr * wi + di * wr;
     } else if constexpr (EPI == EPI_AXPY_NRM_DOT) {
         // v8 := A v6; v5 := alfa v8 + v5; pd += |v5|^2; pz += v3 . v5  (tfqmrgpu_core.hxx:224-228,189)
-        ((R*)a.Y)[off] = yr; ((R*)a.Y)[off + P] = yi;
+        st_stream<STREAM>((R*)a.Y + off, yr); st_stream<STREAM>((R*)a.Y + off + P, yi);
         R* v5 = (R*)a.e0;
-        R ur = v5[off], ui = v5[off + P];
+        R ur = ld_stream<STREAM>(v5 + off), ui = ld_stream<STREAM>(v5 + off + P);
         R const nr = sr * yr - si * yi + ur, ni = si * yr + sr * yi + ui;
-        v5[off] = nr; v5[off + P] = ni;
-        double const wr = a.v3[off], wi = a.v3[off + P], dr = nr, di = ni;
+        st_stream<STREAM>(v5 + off, nr); st_stream<STREAM>(v5 + off + P, ni);
+        double const wr = ld_stream<STREAM>(a.v3 + off), wi = ld_stream<STREAM>(a.v3 + off + P), dr = nr, di = ni;
         acc[0] += dr * wr - di * wi;
         acc[1] += dr * wi + di * wr;
         acc[2] += dr * dr + di * di;
@@ -218,6 +225,28 @@ __device__ inline void vstore(R* p, R const (&src)[N]) {
         *reinterpret_cast<typename VecOf<R, N>::T*>(p) = v;
     }
 }
+// the same for data that is touched once (epilogue vectors): non-temporal where STREAM (see ld_stream above)
+template <bool STREAM, typename R, int N>
+__device__ inline void vload_stream(R (&dst)[N], R const* p) {
+    if constexpr (!STREAM) vload<R, N>(dst, p);
+    else if constexpr (N == 1) dst[0] = __builtin_nontemporal_load(p);
+    else {
+        auto const v = __builtin_nontemporal_load(reinterpret_cast<typename VecOf<R, N>::T const*>(p));
+#pragma unroll
+        for (int i = 0; i < N; ++i) dst[i] = v[i];
+    }
+}
+template <bool STREAM, typename R, int N>
+__device__ inline void vstore_stream(R* p, R const (&src)[N]) {
+    if constexpr (!STREAM) vstore<R, N>(p, src);
+    else if constexpr (N == 1) __builtin_nontemporal_store(src[0], p);
+    else {
+        typename VecOf<R, N>::T v;
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = src[i];
+        __builtin_nontemporal_store(v, reinterpret_cast<typename VecOf<R, N>::T*>(p));
+    }
+}
 
 // Column map of the MFMA kernel: a lane touches NT block columns (one per accumulator tile).  They are chosen as
 // NT/VW groups of VW NEIGHBOURS, VW * sizeof(R) = 16 bytes where NT allows: tile nt of lane column lc holds block
@@ -280,14 +309,15 @@ struct Slice {
 // the vectors an epilogue reads, for the NT neighbouring elements of one lane in one row
 template <typename R, int EPI, int NT>
 struct EpiOps {
+    static constexpr bool STREAM = (16 * NT * sizeof(R) >= 128);   // a lane group covers whole 128-byte lines
     R ur[NT], ui[NT], xr[NT], xi[NT];
     float wr[NT], wi[NT];
     __device__ inline void load(SpmmArgs const& a, size_t off, int P) {
         if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
-            vload<R, NT>(ur, (R const*)a.e0 + off); vload<R, NT>(ui, (R const*)a.e0 + off + P);
-            vload<float, NT>(wr, a.v3 + off); vload<float, NT>(wi, a.v3 + off + P);
+            vload_stream<STREAM, R, NT>(ur, (R const*)a.e0 + off); vload_stream<STREAM, R, NT>(ui, (R const*)a.e0 + off + P);
+            vload_stream<STREAM, float, NT>(wr, a.v3 + off); vload_stream<STREAM, float, NT>(wi, a.v3 + off + P);
         }
-        if constexpr (EPI == EPI_XPAY_DOT) { vload<R, NT>(xr, (R const*)a.e1 + off); vload<R, NT>(xi, (R const*)a.e1 + off + P); }
+        if constexpr (EPI == EPI_XPAY_DOT) { vload_stream<STREAM, R, NT>(xr, (R const*)a.e1 + off); vload_stream<STREAM, R, NT>(xi, (R const*)a.e1 + off + P); }
     }
 };
 
@@ -298,7 +328,7 @@ __device__ inline void epilogue_row(SpmmArgs const& a, size_t off, int P, R cons
                                     R const (&sr)[NT], R const (&si)[NT], int n0, EpiOps<R, EPI, VW> const& o,
                                     uint32_t bq, int eoff, double (&part)[NPL > 0 ? NPL : 1][NT])
 {
-    if constexpr (EPI != EPI_RESIDUAL) { vstore<R, VW>((R*)a.Y + off, yr); vstore<R, VW>((R*)a.Y + off + P, yi); }
+    if constexpr (EPI != EPI_RESIDUAL) { vstore_stream<EpiOps<R, EPI, VW>::STREAM, R, VW>((R*)a.Y + off, yr); vstore_stream<EpiOps<R, EPI, VW>::STREAM, R, VW>((R*)a.Y + off + P, yi); }
     if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
         R nr[VW], ni[VW];
 #pragma unroll
@@ -315,7 +345,7 @@ __device__ inline void epilogue_row(SpmmArgs const& a, size_t off, int P, R cons
             part[1][n0 + n] += dr * wi + di * wr;
             if constexpr (EPI == EPI_AXPY_NRM_DOT) part[2][n0 + n] += dr * dr + di * di;
         }
-        vstore<R, VW>((R*)a.e0 + off, nr); vstore<R, VW>((R*)a.e0 + off + P, ni);
+        vstore_stream<EpiOps<R, EPI, VW>::STREAM, R, VW>((R*)a.e0 + off, nr); vstore_stream<EpiOps<R, EPI, VW>::STREAM, R, VW>((R*)a.e0 + off + P, ni);
     } else if constexpr (EPI == EPI_RESIDUAL) {
         R br[VW] = {}, bi[VW] = {};
         if (bq != 0xffffffffu) {
@@ -545,7 +575,7 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
             R const yi = tile[wave][ei][ej + 8] + tile[wave][ei + 8][ej];
             int const e = ei * LN + nt * 8 + ej;
             double accp[NPL > 0 ? NPL : 1] = {};
-            epilogue<R, EPI>(a, size_t(y) * 2 * P + e, P, yr, yi, sr[nt], si[nt], bq, e, accp);
+            epilogue<R, EPI, LN == 8>(a, size_t(y) * 2 * P + e, P, yr, yi, sr[nt], si[nt], bq, e, accp);   // LN == 8: the tile is one contiguous plane
 #pragma unroll
             for (int p = 0; p < NPL; ++p) part[p][nt] += accp[p];
         }
