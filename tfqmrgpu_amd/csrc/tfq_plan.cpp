@@ -227,12 +227,12 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     size_t const blockElems = size_t(2) * LM * LN;
     p.S = size_t(p.nnzbX) * blockElems * p.realBytes;
 
-    // chunks: runs of CH blocks inside one column, sized so that a chunk of one vector is 8..64 KiB and the
+    // chunks: runs of CH blocks inside one column, sized so that a chunk of one vector is 8..16 KiB and the
     // grid has a few thousand work groups when the problem is large enough
     {
         size_t const blockBytes = blockElems * p.realBytes;
         size_t target = p.S / 4096;
-        size_t maxKiB = 64;
+        size_t maxKiB = 16;   // P2: 64 -> 16 KiB takes the vector kernels from 4.2 to 17 rounds of work groups (tail 16 % -> 1 %): iteration 2.80 -> 2.69 ms
         if (auto v = std::getenv("TFQMRGPU_CHUNK_KIB")) maxKiB = std::max(8, std::atoi(v));
         target = std::min<size_t>(std::max<size_t>(target, 8 * 1024), maxKiB * 1024);
         uint32_t CH = uint32_t(std::max<size_t>(1, target / blockBytes));
