@@ -40,6 +40,27 @@ __global__ __launch_bounds__(256) void k_triad(double2* __restrict__ y, double2 
         y[i] = c;
     }
 }
+using d2 = __attribute__((ext_vector_type(2))) double;
+// the same streams with non-temporal accesses (what the solver's vector kernels use)
+__global__ __launch_bounds__(256) void k_copy_nt(d2* __restrict__ y, d2 const* __restrict__ x, size_t n) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(x + i), y + i);
+}
+__global__ __launch_bounds__(256) void k_triad_nt(d2* __restrict__ y, d2 const* __restrict__ x, d2 const* __restrict__ z, size_t n) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        d2 const a = __builtin_nontemporal_load(x + i), b = __builtin_nontemporal_load(z + i), c = __builtin_nontemporal_load(y + i);
+        __builtin_nontemporal_store(a + 1.5 * b - 0.5 * c, y + i);
+    }
+}
+// 4 read streams + 3 write streams, the shape of k_x_v6_v7
+__global__ __launch_bounds__(256) void k_seven_nt(d2* __restrict__ a, d2* __restrict__ b, d2* __restrict__ c, d2 const* __restrict__ d, size_t n) {
+    for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+        d2 const va = __builtin_nontemporal_load(a + i), vb = __builtin_nontemporal_load(b + i), vc = __builtin_nontemporal_load(c + i), vd = __builtin_nontemporal_load(d + i);
+        __builtin_nontemporal_store(va + 0.5 * vd, a + i);
+        __builtin_nontemporal_store(vb + 0.25 * va, b + i);
+        __builtin_nontemporal_store(vc - 0.5 * vb, c + i);
+    }
+}
 template <class F> float timeit(F f, int reps) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     f(); hipDeviceSynchronize();
@@ -64,6 +85,15 @@ int main() {
         printf("copy  16 B/lane, %6d WGs: %.3f ms  %.0f GB/s\n", wg, ms, 2.0 * n * 16 / ms * 1e-6);
         ms = timeit([&] { k_triad<<<wg, 256>>>(y, x, z, n); }, 5);
         printf("triad 16 B/lane, %6d WGs: %.3f ms  %.0f GB/s\n", wg, ms, 4.0 * n * 16 / ms * 1e-6);
+    }
+    double2* w; hipMalloc(&w, n * 16); hipMemset(w, 0, n * 16);
+    for (int wg : {2048, 16384, 65536, 262144}) {
+        float ms = timeit([&] { k_copy_nt<<<wg, 256>>>((d2*)y, (d2 const*)x, n); }, 5);
+        printf("copy  16 B/lane non-temporal, %6d WGs: %.3f ms  %.0f GB/s\n", wg, ms, 2.0 * n * 16 / ms * 1e-6);
+        ms = timeit([&] { k_triad_nt<<<wg, 256>>>((d2*)y, (d2 const*)x, (d2 const*)z, n); }, 5);
+        printf("triad 16 B/lane non-temporal, %6d WGs: %.3f ms  %.0f GB/s\n", wg, ms, 4.0 * n * 16 / ms * 1e-6);
+        ms = timeit([&] { k_seven_nt<<<wg, 256>>>((d2*)x, (d2*)y, (d2*)z, (d2 const*)w, n); }, 5);
+        printf("4 in + 3 out non-temporal,    %6d WGs: %.3f ms  %.0f GB/s\n", wg, ms, 7.0 * n * 16 / ms * 1e-6);
     }
     return 0;
 }
