@@ -441,6 +441,7 @@ tfqmrgpuStatus_t tfqmrgpu_bsrsv_bufferSize(tfqmrgpuHandle_t handle, tfqmrgpuBsrs
     if (!blockSizeAllowed(LM, LN)) return err(TFQMRGPU_BLOCKSIZE_MISSING, LN, LM); // tfqmrgpu.cu:70
     // 'm' is accepted here and refused by solve, as in the reference (tfqmrgpu.cu:42-44); size it like 'c'
     auto const st = layoutBuffer(*p, LM, LN, ('m' == prec) ? 'c' : prec);
+    if (p->opScratch) { (void)hipFree(p->opScratch); p->opScratch = nullptr; }   // sized for the previous block shape
     p->precision = prec;
     p->buffer = nullptr;
     *pBufferSizeInBytes = p->bufferBytes;
