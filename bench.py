@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--max-iterations", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--multiply-reps", type=int, default=20)
+    ap.add_argument("--no-hbm-multiply", action="store_true", help="skip the one-block-column (HBM-bound) multiply measurement")
     args = ap.parse_args()
 
     import torch
@@ -251,6 +252,47 @@ def main():
             rm.update(kernel="multiply (Y = A*X, no epilogue)", avg_ms=round(mms, 5), launches=args.multiply_reps,
                       algorithmic_bytes=int(model["multiply"][0]), algorithmic_flops=float(model["multiply"][1]))
 
+            # the HBM-bound corner of the same multiply kernel: the operator applied to ONE block column, every A block
+            # used once (arithmetic intensity 5.8 flop/B for 16x16 z, ridge 9.8).  Index lists of a 5-point block stencil
+            # on a 384 x 384 grid, values random on the device.
+            rh = None
+            if prec == "z" and pr.LM == 16 and pr.LN == 16 and not args.no_hbm_multiply:
+                n1 = 384
+                ix, iy = np.meshgrid(np.arange(n1), np.arange(n1), indexing="ij")
+                rows, nbr = [], []
+                for dx, dy in ((0, 0), (1, 0), (-1, 0), (0, 1), (0, -1)):
+                    ok = (ix + dx >= 0) & (ix + dx < n1) & (iy + dy >= 0) & (iy + dy < n1)
+                    rows.append((ix * n1 + iy)[ok]); nbr.append(((ix + dx) * n1 + iy + dy)[ok])
+                rows, nbr = np.concatenate(rows), np.concatenate(nbr)
+                o = np.argsort(rows, kind="stable")
+                rows, nbr = rows[o], nbr[o]
+                nY1, nP1 = n1 * n1, len(rows)
+                st1 = np.zeros(nY1 + 1, np.int64); np.add.at(st1, rows + 1, 1); st1 = np.cumsum(st1).astype(np.uint32)
+                pa1 = np.stack([np.arange(nP1), nbr], axis=1).astype(np.uint32).reshape(-1)
+                A1 = torch.rand((nP1, 2, 16, 16), dtype=real, device="cuda") - 0.5
+                X1 = torch.rand((nY1, 2, 16, 16), dtype=real, device="cuda") - 0.5
+                Y1 = torch.empty_like(X1)
+                dS1, dP1 = torch.from_numpy(st1.view(np.int32)).cuda(), torch.from_numpy(pa1.view(np.int32)).cuda()
+
+                def mult1():
+                    T._check(T.lib.tfqmrgpuExt_multiply(s.handle, b"z", 16, 16, nY1, dS1.data_ptr(), dP1.data_ptr(),
+                                                        A1.data_ptr(), X1.data_ptr(), Y1.data_ptr()), "tfqmrgpuExt_multiply")
+                for _ in range(5):
+                    mult1()
+                e0.record(stream)
+                for _ in range(args.multiply_reps):
+                    mult1()
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ms1 = e0.elapsed_time(e1) / args.multiply_reps
+                b1 = (nP1 + 2 * nY1) * 2 * 16 * 16 * 8 + 4 * (nY1 + 1) + 8 * nP1
+                f1 = nP1 * 8.0 * 16 * 16 * 16
+                rh = dict(bound="hbm", achieved=round(b1 / (ms1 * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                          frac=round(b1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), tflops=round(f1 / (ms1 * 1e-3) / 1e12, 3),
+                          kernel="multiply, operator on one block column (5-point block stencil 384x384, every A block used once)",
+                          avg_ms=round(ms1, 5), launches=args.multiply_reps, algorithmic_bytes=int(b1), algorithmic_flops=f1)
+                del A1, X1, Y1
+
             S = pr.nnzbX * 2 * pr.LM * pr.LN * (8 if prec == "z" else 4)
             it_bytes = sum(model[k][0] for k in ("xpay_v6", "spmm_v4_dot", "v5_nrm", "x_v6_v7", "spmm_v5_nrm_dot"))
             it_ms = sum(v["total_ms"] for k, v in per_kernel.items() if k != "probe") / max(1, iters)
@@ -272,6 +314,7 @@ def main():
                 "buffer_GB_per_gpu": round(nbytes / 1e9, 3), "vector_MB": round(S / 1e6, 1),
                 "roofline": rl,
                 "roofline_multiply": rm,
+                "roofline_multiply_hbm_bound": rh,
                 "roofline_iteration": dict(bound="hbm", achieved=round(it_bytes / (it_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                                            frac=round(it_bytes / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), ms_per_iteration=round(it_ms, 4),
                                            algorithmic_bytes=int(it_bytes)),
