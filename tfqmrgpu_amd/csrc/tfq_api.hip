@@ -179,6 +179,20 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
 
     p.boundHistory.clear();
     p.iterations_needed = maxIt; p.flops_performed = 0;
+    // How far the host runs ahead.  Every slot that is still queued when the solve stops costs ~14 empty launches, so
+    // the queue is only as deep as hiding the host needs: an iteration that streams >= 32 MiB per vector takes >= 0.3 ms,
+    // far longer than enqueuing the next one (~50 us), and two slots in flight are enough; small systems, whose
+    // iterations are as short as the enqueue itself, keep all DEPTH slots.
+    static int const depthEnv = [] { auto v = std::getenv("TFQMRGPU_DEPTH"); return v ? std::atoi(v) : 0; }();
+    int ahead = (depthEnv >= 1 && depthEnv <= DEPTH) ? depthEnv : (p.S >= (size_t(32) << 20)) ? 2 : DEPTH;
+    if (multi) {   // every rank must enqueue the same number of slots (the collectives have to match): the deepest wish wins
+        double vote[2] = { double(ahead), 0. };
+        TFQ_HIP(hipMemcpyAsync(&d.ctl->red[0], vote, sizeof vote, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        if (auto const st = reduce_over_ranks(h, d, 0, s)) return st;
+        TFQ_HIP(hipMemcpyAsync(vote, &d.ctl->red[0], sizeof vote, hipMemcpyDeviceToHost, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        ahead = std::min(DEPTH, std::max(1, int(vote[0])));
+    }
     vec_launch(VEC_SETUP, d, tol, maxIt, s);
 
     tfqmrgpuStatus_t fail = TFQMRGPU_STATUS_SUCCESS;
@@ -272,7 +286,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
             }
         }
     } else
-    while (enq < std::min(DEPTH, maxIt)) { enqueue(enq % DEPTH); ++enq; }
+    while (enq < std::min(ahead, maxIt)) { enqueue(enq % DEPTH); ++enq; }
     while (seen < enq && !fail) {
         int const slot = seen % DEPTH;
         if (hipSuccess != hipEventSynchronize(ev[slot])) { fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED); break; }
