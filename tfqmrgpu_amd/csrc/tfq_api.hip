@@ -179,12 +179,12 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
 
     p.boundHistory.clear();
     p.iterations_needed = maxIt; p.flops_performed = 0;
-    // How far the host runs ahead.  Every slot that is still queued when the solve stops costs ~14 empty launches, so
-    // the queue is only as deep as hiding the host needs: an iteration that streams >= 32 MiB per vector takes >= 0.3 ms,
-    // far longer than enqueuing the next one (~50 us), and two slots in flight are enough; small systems, whose
-    // iterations are as short as the enqueue itself, keep all DEPTH slots.
+    // How far the host runs ahead: 2 slots.  Every slot that is still queued when the solve stops costs ~14 empty
+    // launches, and enqueuing a slot (~50 us) is never slower than executing one (>= 60 us even for tiny systems), so a
+    // deeper queue only adds to the tail (measured: 4 -> 2 gains 8 % on the 2-iteration solves of config 3, 5 % on
+    // 1000-block systems, 0.8 % on P2; 1 loses on small systems).  TFQMRGPU_DEPTH = 1..4 overrides.
     static int const depthEnv = [] { auto v = std::getenv("TFQMRGPU_DEPTH"); return v ? std::atoi(v) : 0; }();
-    int ahead = (depthEnv >= 1 && depthEnv <= DEPTH) ? depthEnv : (p.S >= (size_t(32) << 20)) ? 2 : DEPTH;
+    int ahead = (depthEnv >= 1 && depthEnv <= DEPTH) ? depthEnv : 2;
     if (multi) {   // every rank must enqueue the same number of slots (the collectives have to match): the deepest wish wins
         double vote[2] = { double(ahead), 0. };
         TFQ_HIP(hipMemcpyAsync(&d.ctl->red[0], vote, sizeof vote, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
