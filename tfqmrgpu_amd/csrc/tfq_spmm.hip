@@ -15,8 +15,9 @@
 //    global -> VGPR fully coalesced with no LDS transpose.  With several 16-column tiles per strip a lane
 //    owns NEIGHBOURING columns (ColMap below) and moves them as one 16-byte access.  4 real MFMA chains
 //    per complex product (-Im(A) is formed once per operand).
-//  * k_spmm_mfma8 : LM == 8, LN multiple of 8: [Re A; Im A] x [Re X | Im X] fills one 16 x 16 tile.
-//  * k_spmm_direct : every other block shape (LM == 4, LN in {9, 10}); one thread per output element,
+//  * k_spmm_mfma8 : LM == 8: [Re A; Im A] x [Re X | Im X] fills one 16 x 16 tile per 8 block columns (LN = 9, 10: the
+//    second tile is masked down to 1 or 2 columns -- the matrix pipe is idle in these HBM-bound shapes anyway).
+//  * k_spmm_direct : LM == 4; one thread per output element,
 //    operands through the vector L1.
 // A work group processes one chunk (run of Y blocks of one block column, tfq_plan.cpp), so the
 // per-RHS scalars of the epilogue are uniform and the dot / norm contributions leave the work group
@@ -528,9 +529,9 @@ __global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at leas
 template <typename R, int LN, int EPI>
 __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
     if (gate_closed(a)) return;
-    constexpr int LM = 8, P = LM * LN, NT = LN / 8;
+    constexpr int LM = 8, P = LM * LN, NT = (LN + 7) / 8;   // LN = 9, 10: the second tile has 1 or 2 columns, the rest is masked
     constexpr int NPL = EpiPlanes<EPI>::N;
-    static_assert(LN % 8 == 0, "8-column tiles");
+    constexpr bool RAGGED = (LN % 8 != 0);
     using T4 = typename Acc<R>::T;
     __shared__ R tile[4][16][17];                      // one patch per wave, padded rows
     int const lane = threadIdx.x & 63;
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
     for (int nt = 0; nt < NT; ++nt) { sr[nt] = 0; si[nt] = 0; }
     if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) if (!RAGGED || nt * 8 + ej < LN) {
             sr[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + nt * 8 + ej];
             si[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + nt * 8 + ej];
         }
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
                 int const k = 4 * s + lr;
                 o.a[s] = Ab[k * LM];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) o.x[s][nt] = Xb[k * LN + nt * 8];
+                for (int nt = 0; nt < NT; ++nt) o.x[s][nt] = (!RAGGED || nt * 8 + j8 < LN) ? Xb[k * LN + nt * 8] : R(0);
             }
         };
         auto mma = [&](Ops const& o) {
@@ -608,7 +609,8 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
             R const yi = tile[wave][ei][ej + 8] + tile[wave][ei + 8][ej];
             int const e = ei * LN + nt * 8 + ej;
             double accp[NPL > 0 ? NPL : 1] = {};
-            epilogue<R, EPI, LN == 8>(a, size_t(y) * 2 * P + e, P, yr, yi, sr[nt], si[nt], bq, e, accp);   // LN == 8: the tile is one contiguous plane
+            if (!RAGGED || nt * 8 + ej < LN)
+                epilogue<R, EPI, LN == 8>(a, size_t(y) * 2 * P + e, P, yr, yi, sr[nt], si[nt], bq, e, accp);   // LN == 8: the tile is one contiguous plane
 #pragma unroll
             for (int p = 0; p < NPL; ++p) part[p][nt] += accp[p];
         }
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
                 v += __shfl_xor(v, 8);
                 v += __shfl_xor(v, 16);
                 v += __shfl_xor(v, 32);
-                if (lane < 8) s[wave][p][nt * 8 + lane] = v;
+                if (lane < 8 && (!RAGGED || nt * 8 + lane < LN)) s[wave][p][nt * 8 + lane] = v;
             }
         __syncthreads();
         for (int e = threadIdx.x; e < NPL * LN; e += 256) {
@@ -656,7 +658,7 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
             if (pre && use_pre) k_spmm_mfma<R, LM, LN, EPI, pre, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
             else k_spmm_mfma<R, LM, LN, EPI, false, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
         }
-    } else if constexpr (LM == 8 && LN % 8 == 0) k_spmm_mfma8<R, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
+    } else if constexpr (LM == 8) k_spmm_mfma8<R, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
     else k_spmm_direct<R, LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
 }
 
@@ -736,7 +738,7 @@ tfqmrgpuStatus_t launch_multiply(char precision, int lm, int ln, uint32_t nnzbY,
     int const mu = mt / ms;                               // strips per Y block
     uint32_t ch = (mu >= 4) ? 1 : 4 / mu;                 // one strip per wave
     if (!mfma) ch = (lm * ln >= 256) ? 1 : 256 / (lm * ln); // one Y block per thread group
-    if (8 == lm && ln % 8 == 0) ch = 4;                     // k_spmm_mfma8: one Y block per wave
+    if (8 == lm) ch = 4;                                    // k_spmm_mfma8: one Y block per wave
     a.CH = ch;
     uint32_t const nWG = (nnzbY + ch - 1) / ch;
     if (!spmm_dispatch(dbl, lm, ln, EPI_NONE, a, nWG, s))
