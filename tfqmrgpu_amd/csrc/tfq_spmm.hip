@@ -15,9 +15,9 @@
 //    global -> VGPR fully coalesced with no LDS transpose.  With several 16-column tiles per strip a lane
 //    owns NEIGHBOURING columns (ColMap below) and moves them as one 16-byte access.  4 real MFMA chains
 //    per complex product (-Im(A) is formed once per operand).
-//  * k_spmm_mfma8 : LM == 8: [Re A; Im A] x [Re X | Im X] fills one 16 x 16 tile per 8 block columns (LN = 9, 10: the
-//    second tile is masked down to 1 or 2 columns -- the matrix pipe is idle in these HBM-bound shapes anyway).
-//  * k_spmm_direct : LM == 4; one thread per output element,
+//  * k_spmm_mfma8 : LM == 8 or 4: [Re A; Im A] x [Re X | Im X] fills one 16 x 16 tile per 8 block columns (LN = 5, 9, 10:
+//    the last tile is masked; LM == 4: half of the rows are empty -- the matrix pipe is idle in these HBM-bound shapes).
+//  * k_spmm_direct : one thread per output element; only as the epilogue of a user-defined operator,
 //    operands through the vector L1.
 // A work group processes one chunk (run of Y blocks of one block column, tfq_plan.cpp), so the
 // per-RHS scalars of the epilogue are uniform and the dot / norm contributions leave the work group
@@ -526,10 +526,12 @@ __global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at leas
 // A[c = (l%16)/8][k0 + l/16][(l%16)%8] and X[c = (l%16)/8][k0 + l/16][8 nt + (l%16)%8].
 // After the pair loop the tile goes through a wave-private LDS patch and comes back as one complex
 // element per lane:  Y = (Q00 - Q11) + i (Q01 + Q10),  lane l <-> element (row l/8, column l%8).
-template <typename R, int LN, int EPI>
+template <typename R, int LM, int LN, int EPI>
 __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
     if (gate_closed(a)) return;
-    constexpr int LM = 8, P = LM * LN, NT = (LN + 7) / 8;   // LN = 9, 10: the second tile has 1 or 2 columns, the rest is masked
+    static_assert(LM == 4 || LM == 8, "[Re A; Im A] must fit the 16 rows of a tile");
+    constexpr int P = LM * LN, NT = (LN + 7) / 8;   // LN = 5, 9, 10: the last tile has 5, 1 or 2 columns, the rest is masked
+    constexpr int KS = LM / 4;                       // MFMA k-steps per block product
     constexpr int NPL = EpiPlanes<EPI>::N;
     constexpr bool RAGGED = (LN % 8 != 0);
     using T4 = typename Acc<R>::T;
@@ -537,8 +539,9 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
     int const lane = threadIdx.x & 63;
     int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int const lr = lane >> 4, lc = lane & 15;
-    int const part8 = lc >> 3, j8 = lc & 7;            // operand side: plane and column inside the tile
-    int const ei = lane >> 3, ej = lane & 7;           // epilogue side: element (ei, ej) of the 8 x 8 tile
+    int const part8 = lc >> 3, j8 = lc & 7;            // X operand: plane and column inside the tile
+    int const pa = lc / LM, ia = lc % LM;              // A operand: plane (LM == 4: lanes with pa >= 2 feed zeros) and row
+    int const ei = lane >> 3, ej = lane & 7;           // epilogue side: element (ei, ej) of the LM x 8 tile (ei < LM)
     uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;   // XCD-aware launch order (tfq_plan.cpp)
     uint32_t first, last, col = 0;
     if (a.chunkFirst) { first = a.chunkFirst[chunk]; last = a.chunkFirst[chunk + 1]; col = a.chunkCol[chunk]; }
@@ -556,8 +559,8 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
     }
     double part[NPL > 0 ? NPL : 1][NT] = {};
 
-    struct Ops { R a[2]; R x[2][NT]; };
-    R const* const A0 = (R const*)a.A + part8 * (LM * LM) + j8;      // + k*8
+    struct Ops { R a[KS]; R x[KS][NT]; };
+    R const* const A0 = (R const*)a.A + (pa & 1) * (LM * LM) + ia;   // + k*LM
     R const* const X0 = (R const*)a.X + part8 * P + j8;              // + k*LN + nt*8
     for (uint32_t y = first + wave; y < last; y += 4) {
         T4 acc[NT];
@@ -568,16 +571,16 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
             R const* Ab = A0 + size_t(a.pairs[2 * size_t(q)]) * 2 * LM * LM;
             R const* Xb = X0 + size_t(a.pairs[2 * size_t(q) + 1]) * 2 * P;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+            for (int s = 0; s < KS; ++s) {
                 int const k = 4 * s + lr;
-                o.a[s] = Ab[k * LM];
+                o.a[s] = (LM == 8 || pa < 2) ? Ab[k * LM] : R(0);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) o.x[s][nt] = (!RAGGED || nt * 8 + j8 < LN) ? Xb[k * LN + nt * 8] : R(0);
             }
         };
         auto mma = [&](Ops const& o) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < KS; ++s)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[nt] = Acc<R>::mma(o.a[s], o.x[s][nt], acc[nt]);
         };
@@ -605,11 +608,12 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) tile[wave][Acc<R>::row(lane, r)][lc] = acc[nt][r];
             __builtin_amdgcn_wave_barrier();           // LDS operations of one wave complete in order
-            R const yr = tile[wave][ei][ej] - tile[wave][ei + 8][ej + 8];
-            R const yi = tile[wave][ei][ej + 8] + tile[wave][ei + 8][ej];
+            int const er = ei % LM;                    // LM == 4: the upper half of the lanes has no element
+            R const yr = tile[wave][er][ej] - tile[wave][er + LM][ej + 8];
+            R const yi = tile[wave][er][ej + 8] + tile[wave][er + LM][ej];
             int const e = ei * LN + nt * 8 + ej;
             double accp[NPL > 0 ? NPL : 1] = {};
-            if (!RAGGED || nt * 8 + ej < LN)
+            if ((LM == 8 || ei < LM) && (!RAGGED || nt * 8 + ej < LN))
                 epilogue<R, EPI, LN == 8>(a, size_t(y) * 2 * P + e, P, yr, yi, sr[nt], si[nt], bq, e, accp);   // LN == 8: the tile is one contiguous plane
 #pragma unroll
             for (int p = 0; p < NPL; ++p) part[p][nt] += accp[p];
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
     }
 
     if constexpr (NPL > 0) {
-        // the 8 rows of a column sit 8 lanes apart: add them, then the four waves in order
+        // the rows of a column sit 8 lanes apart: add them, then the four waves in order
         __shared__ double s[4][NPL][LN];
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
@@ -637,6 +641,12 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
         }
     }
 }
+
+// which shapes take k_spmm_mfma8: all 8-row ones; of the 4-row ones those where the half-empty tile still beats one thread
+// per element (measured, 5-point stencils of 256 MB per vector, multiply / iteration in ms, direct -> tile: 4x5 z 0.76/2.71 ->
+// 0.65/2.46, 4x8 z 0.71/2.35 -> 0.42/1.84, 4x32 z 0.67/2.35 -> 0.24/1.62; but 4x4 z 0.74/2.44 -> 0.79/2.62 and every float
+// shape slower: 4x4 c 0.53/2.55 -> 1.39/4.25 -- a wave then moves too few bytes per memory instruction)
+template <typename R, int LM, int LN> constexpr bool kTile8 = (LM == 8) || (LM == 4 && sizeof(R) == 8 && LN > 4);
 
 // ---------------------------------------------------------------------------------------------------
 template <typename R, int LM, int LN, int EPI>
@@ -658,7 +668,7 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
             if (pre && use_pre) k_spmm_mfma<R, LM, LN, EPI, pre, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
             else k_spmm_mfma<R, LM, LN, EPI, false, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
         }
-    } else if constexpr (LM == 8) k_spmm_mfma8<R, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
+    } else if constexpr (kTile8<R, LM, LN>) k_spmm_mfma8<R, LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
     else k_spmm_direct<R, LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
 }
 
@@ -738,7 +748,7 @@ tfqmrgpuStatus_t launch_multiply(char precision, int lm, int ln, uint32_t nnzbY,
     int const mu = mt / ms;                               // strips per Y block
     uint32_t ch = (mu >= 4) ? 1 : 4 / mu;                 // one strip per wave
     if (!mfma) ch = (lm * ln >= 256) ? 1 : 256 / (lm * ln); // one Y block per thread group
-    if (8 == lm) ch = 4;                                    // k_spmm_mfma8: one Y block per wave
+    if (8 == lm || (4 == lm && dbl && ln > 4)) ch = (4 == lm) ? 16 : 4;   // k_spmm_mfma8 (kTile8): one Y block per wave and pass
     a.CH = ch;
     uint32_t const nWG = (nnzbY + ch - 1) / ch;
     if (!spmm_dispatch(dbl, lm, ln, EPI_NONE, a, nWG, s))
