@@ -15,8 +15,9 @@
 //    global -> VGPR fully coalesced with no LDS transpose.  With several 16-column tiles per strip a lane
 //    owns NEIGHBOURING columns (ColMap below) and moves them as one 16-byte access.  4 real MFMA chains
 //    per complex product (-Im(A) is formed once per operand).
-//  * k_spmm_mfma8 : LM == 8 or 4: [Re A; Im A] x [Re X | Im X] fills one 16 x 16 tile per 8 block columns (LN = 5, 9, 10:
-//    the last tile is masked; LM == 4: half of the rows are empty -- the matrix pipe is idle in these HBM-bound shapes).
+//  * k_spmm_mfma8 : LM == 8 (and 4 x 32 z): [Re A; Im A] x [Re X | Im X] fills one 16 x 16 tile per 8 block columns (LN = 9,
+//    10: the last tile is masked; LM == 4: half of the rows are empty -- the matrix pipe is idle in these HBM-bound shapes).
+//  * k_spmm_small4 : the other 4-row shapes: one lane per element, operands once per thread group through LDS.
 //  * k_spmm_direct : one thread per output element; only as the epilogue of a user-defined operator,
 //    operands through the vector L1.
 // A work group processes one chunk (run of Y blocks of one block column, tfq_plan.cpp), so the
@@ -642,11 +643,100 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
     }
 }
 
-// which shapes take k_spmm_mfma8: all 8-row ones; of the 4-row ones those where the half-empty tile still beats one thread
-// per element (measured, 5-point stencils of 256 MB per vector, multiply / iteration in ms, direct -> tile: 4x5 z 0.76/2.71 ->
-// 0.65/2.46, 4x8 z 0.71/2.35 -> 0.42/1.84, 4x32 z 0.67/2.35 -> 0.24/1.62; but 4x4 z 0.74/2.44 -> 0.79/2.62 and every float
-// shape slower: 4x4 c 0.53/2.55 -> 1.39/4.25 -- a wave then moves too few bytes per memory instruction)
-template <typename R, int LM, int LN> constexpr bool kTile8 = (LM == 8) || (LM == 4 && sizeof(R) == 8 && LN > 4);
+// ---------------------------------------------------------------------------------------------------
+// 4-row blocks that are too small for the tile kernel (4 x 4, and the float 4-row shapes: a block is 128 ... 1024 bytes).
+// A thread group of 16, 32 or 64 lanes owns one sub-block of 4 x min(LN, 16) elements, one element per lane; the operands
+// of a block product are read ONCE per group (4 memory instructions per wave and product instead of 16 per lane in
+// k_spmm_direct), pass through a group-private LDS patch and are broadcast from there.  Groups never straddle a wave and
+// LDS operations of one wave complete in order, so no barrier is needed inside the product loop.
+template <typename R, int LN, int EPI>
+__global__ __launch_bounds__(256) void k_spmm_small4(SpmmArgs a) {
+    if (gate_closed(a)) return;
+    constexpr int LM = 4, P = LM * LN;
+    constexpr int LNS = (LN > 16) ? 16 : LN;             // columns of a sub-block
+    constexpr int NSUB = LN / LNS;                       // sub-blocks per block (LN = 32: 2)
+    constexpr int PE = LM * LNS;                         // elements of a sub-block: 16, 20, 32, 64
+    constexpr int PG = (PE <= 16) ? 16 : (PE <= 32) ? 32 : 64;   // lanes of a thread group
+    constexpr int NG = 256 / PG;                         // thread groups per work group
+    constexpr int NPL = EpiPlanes<EPI>::N;
+    static_assert(LN % LNS == 0 && NG % NSUB == 0, "a thread group keeps its sub-block index");
+    __shared__ R As[NG][2][LM * LM];
+    __shared__ R Xs[NG][2][PE];
+    int const t = threadIdx.x, g = t / PG, e = t % PG;
+    bool const valid = (e < PE);
+    int const i = valid ? e / LNS : 0, jj = valid ? e % LNS : 0;
+    int const j = (g % NSUB) * LNS + jj;                 // block column of this lane
+    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;   // XCD-aware launch order (tfq_plan.cpp)
+    uint32_t first, last, col = 0;
+    if (a.chunkFirst) { first = a.chunkFirst[chunk]; last = a.chunkFirst[chunk + 1]; col = a.chunkCol[chunk]; }
+    else { first = chunk * a.CH; last = min(first + a.CH, a.nY); }
+
+    R sr = 0, si = 0;
+    if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
+        sr = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + j];
+        si = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + j];
+    }
+    double part[NPL > 0 ? NPL : 1] = {};
+
+    uint32_t const nItems = (last - first) * NSUB;       // item = sub-block of a Y block; item % NSUB == g % NSUB
+    for (uint32_t it = g; it < nItems; it += NG) {
+        uint32_t const y = first + it / NSUB;
+        uint32_t const q0 = a.starts[y], q1 = a.starts[y + 1];
+        R pa[2] = {0, 0}, px[2] = {0, 0};                // operands of the next product, in flight
+        auto fetch = [&](uint32_t q) __attribute__((always_inline)) {
+            R const* Ab = (R const*)a.A + size_t(a.pairs[2 * size_t(q)]) * 2 * (LM * LM);
+            R const* Xb = (R const*)a.X + size_t(a.pairs[2 * size_t(q) + 1]) * 2 * P;
+            if (e < LM * LM) { pa[0] = Ab[e]; pa[1] = Ab[LM * LM + e]; }
+            if (valid) { px[0] = Xb[i * LN + j]; px[1] = Xb[P + i * LN + j]; }
+        };
+        R yr = 0, yi = 0;
+        if (q0 < q1) fetch(q0);
+        for (uint32_t q = q0; q < q1; ++q) {
+            __builtin_amdgcn_wave_barrier();
+            if (e < LM * LM) { As[g][0][e] = pa[0]; As[g][1][e] = pa[1]; }
+            if (valid) { Xs[g][0][e] = px[0]; Xs[g][1][e] = px[1]; }
+            if (q + 1 < q1) fetch(q + 1);
+            __builtin_amdgcn_wave_barrier();
+            R cr = 0, ci = 0;
+#pragma unroll
+            for (int k = 0; k < LM; ++k) {
+                R const ar = As[g][0][k * LM + i], ai = As[g][1][k * LM + i];
+                R const xr = Xs[g][0][k * LNS + jj], xi = Xs[g][1][k * LNS + jj];
+                cr += ar * xr - ai * xi;
+                ci += ar * xi + ai * xr;
+            }
+            yr += cr; yi += ci;
+        }
+        if (valid) {
+            uint32_t bq = 0xffffffffu;
+            if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
+            int const eb = i * LN + j;
+            epilogue<R, EPI, false>(a, size_t(y) * 2 * P + eb, P, yr, yi, sr, si, bq, eb, part);
+        }
+    }
+
+    if constexpr (NPL > 0) {
+        // threads that share a block column: groups with the same sub-block index, 4 rows each; added in a fixed order
+        __shared__ double red[NPL][256];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) red[p][t] = valid ? part[p] : 0.0;
+        __syncthreads();
+        for (int x = t; x < NPL * LN; x += 256) {
+            int const p = x / LN, jx = x % LN;
+            double sum = 0;
+            for (int gg = jx / LNS; gg < NG; gg += NSUB)
+                for (int r = 0; r < LM; ++r) sum += red[p][gg * PG + r * LNS + jx % LNS];
+            write_record<EPI>(a, chunk, LN, p, jx, sum);
+        }
+    }
+}
+
+// which shapes take k_spmm_mfma8: all 8-row ones; of the 4-row ones only 4 x 32 in double -- elsewhere the half-empty tile
+// moves too few bytes per memory instruction and k_spmm_small4 wins (measured, 5-point stencils of 256 MB per vector,
+// multiply / iteration in ms, direct | tile | small4: 4x4 z 0.74/2.44 | 0.79/2.62 | 0.33/1.73, 4x5 z 0.76/2.71 | 0.65/2.46 |
+// 0.51/2.21, 4x8 z 0.71/2.35 | 0.42/1.84 | 0.34/1.65, 4x32 z 0.67/2.35 | 0.24/1.62 | 0.35/1.69, 4x4 c 0.53/2.55 | 1.39/4.25 |
+// 0.45/2.41, 4x5 c 0.97/3.30 | 1.12/3.79 | 0.77/2.82, 4x8 c 0.51/1.96 | 0.72/2.53 | 0.48/2.04, 4x32 c 0.49/1.95 | 0.30/2.10 | 0.45/2.00)
+template <typename R, int LM, int LN> constexpr bool kTile8 = (LM == 8) || (LM == 4 && sizeof(R) == 8 && LN == 32);
 
 // ---------------------------------------------------------------------------------------------------
 template <typename R, int LM, int LN, int EPI>
@@ -669,6 +759,7 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
             else k_spmm_mfma<R, LM, LN, EPI, false, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
         }
     } else if constexpr (kTile8<R, LM, LN>) k_spmm_mfma8<R, LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
+    else if constexpr (LM == 4) k_spmm_small4<R, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
     else k_spmm_direct<R, LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
 }
 
@@ -747,8 +838,8 @@ tfqmrgpuStatus_t launch_multiply(char precision, int lm, int ln, uint32_t nnzbY,
     int const ms = (mt % 2 == 0 && 2 * (ln / 16) * (dbl ? 8 : 4) <= 32) ? 2 : 1;   // RowTiles<>::MS
     int const mu = mt / ms;                               // strips per Y block
     uint32_t ch = (mu >= 4) ? 1 : 4 / mu;                 // one strip per wave
-    if (!mfma) ch = (lm * ln >= 256) ? 1 : 256 / (lm * ln); // one Y block per thread group
-    if (8 == lm || (4 == lm && dbl && ln > 4)) ch = (4 == lm) ? 16 : 4;   // k_spmm_mfma8 (kTile8): one Y block per wave and pass
+    if (!mfma) ch = (4 == lm) ? 64 : (lm * ln >= 256) ? 1 : 256 / (lm * ln); // k_spmm_small4: a few sub-blocks per thread group
+    if (8 == lm || (4 == lm && dbl && 32 == ln)) ch = (4 == lm) ? 16 : 4;   // k_spmm_mfma8 (kTile8): one Y block per wave and pass
     a.CH = ch;
     uint32_t const nWG = (nnzbY + ch - 1) / ch;
     if (!spmm_dispatch(dbl, lm, ln, EPI_NONE, a, nWG, s))
