@@ -1,0 +1,45 @@
+"""The compiled bench_tfqmrgpu (tfqmrgpu_amd/csrc/bench_tfqmrgpu.cpp): the reference's benchmark driver
+(tfQMRgpu/source/bench_tfqmrgpu.cu:442-590) as a C++ caller of the staged C-ABI, same arguments and result lines."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+EXE = os.path.join(ROOT, "tfqmrgpu_amd", "lib", "bench_tfqmrgpu")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_binary_is_built_and_prints_usage():
+    assert os.path.exists(EXE), "make -C tfqmrgpu_amd/csrc builds it"
+    r = subprocess.run([EXE], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "Usage:" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["f", "z"])
+def test_multi_mode_on_the_reference_plan_file(prec):
+    r = subprocess.run([EXE, "multi", os.path.join(GOLD, "plan_unordered.14-287-16.gz"), prec, "3", "2"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    dev = float(re.search(r"# GPU maxdev (\S+)", r.stdout).group(1))
+    assert dev <= (1e-4 if prec == "f" else 1e-11)
+    # 50 526 block products of 16x16x16 complex: the flop count of bench_tfqmrgpu.cu:335
+    tflop = float(re.search(r"# GPU performed (\S+) T", r.stdout).group(1))
+    assert tflop == pytest.approx(6 * 50526 * 8.0 * 16 ** 3 * 1e-12, abs=6e-4)
+    assert re.search(r"# GPU performance \(lm,ln,tune\)=\( 16, 16,0\) is +\S+ G[fF]lop/sec", r.stdout)
+
+
+@pytest.mark.gpu
+def test_tfqmr_mode_matches_the_golden_solve():
+    g = np.load(os.path.join(GOLD, "fd_16x16_small.npz"))
+    r = subprocess.run([EXE, "tfQMR", os.path.join(GOLD, "fd_16x16_small.xml"), "z", "1", "2000"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"# GPU converged to (\S+) in (\d+) iterations", r.stdout)
+    # the default (hash) shadow vector is not the golden run's glibc sequence: same system, nearly the same count
+    assert abs(int(m.group(2)) - int(g["solve_z_iterations"])) <= 3
+    assert float(m.group(1)) <= float(g["solve_z_threshold"])

@@ -1,0 +1,336 @@
+// bench_tfqmrgpu: compiled counterpart of the reference's benchmark driver (real-space/tfQMRgpu
+// tfQMRgpu/source/bench_tfqmrgpu.cu:442-590): same positional arguments, same result lines, a plain C++ caller of
+// libtfQMRgpu.so through include/tfqmrgpu.h (+ tfqmrgpuExt_multiply for the `multi` mode).
+//
+//   bench_tfqmrgpu multi <planfile> [precision=f] [nrep=1] [nsamp=1] [lm=16] [ln=lm]
+//       plan file `#nnzb_for_Y_A_X= nY nA nX` + lines `iY iA iX beta` (bench_tfqmrgpu.cu:456-498), cos/sin fill
+//       (:274-287), host re-computation check maxdev <= 1e-4 (:349-420).  A `.gz` file is read through `gzip -dc`.
+//   bench_tfqmrgpu tfQMR <problem.xml> [precision=z] [nrep=1] [MaxIter=2000]
+//       solves the <LinearProblem> (schema of tfqmrgpu_example_xml_reader.hxx:125-292) through createPlan ->
+//       bufferSize -> setBuffer -> setMatrix -> solve -> getInfo -> getMatrix and compares with the stored X if any
+//       (:178-205).  Blocks of the XML are row-major; transposition flag 'n' (see DESIGN.md on the reference's 't').
+// The XML reader below handles exactly that schema (elements with attributes and whitespace-separated numbers);
+// it is this program's own, the reference uses RapidXML.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "tfqmrgpu.h"
+#include "tfqmrgpu_ext.h"
+
+namespace {
+
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+#define CHECK_HIP(call) do { hipError_t const e_ = (call); if (e_ != hipSuccess) { \
+    std::fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #call, hipGetErrorString(e_)); std::exit(3); } } while (0)
+#define CHECK_TFQ(call) do { tfqmrgpuStatus_t const s_ = (call); if (s_ != TFQMRGPU_STATUS_SUCCESS) { \
+    tfqmrgpuPrintError(s_); std::fprintf(stderr, "%s:%d %s failed with status %d\n", __FILE__, __LINE__, #call, int(s_)); std::exit(2); } } while (0)
+
+std::string slurp(std::string const& path) {
+    if (path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0) {
+        std::string const cmd = "gzip -dc '" + path + "'";
+        FILE* p = popen(cmd.c_str(), "r");
+        if (!p) { std::fprintf(stderr, "cannot run %s\n", cmd.c_str()); std::exit(1); }
+        std::string s; char buf[1 << 16]; size_t n;
+        while ((n = fread(buf, 1, sizeof buf, p)) > 0) s.append(buf, n);
+        pclose(p);
+        return s;
+    }
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { std::fprintf(stderr, "cannot open '%s'\n", path.c_str()); std::exit(1); }
+    std::ostringstream ss; ss << f.rdbuf();
+    return ss.str();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// multi mode
+int bench_multi(int argc, char** argv) {
+    std::string const path = (argc > 2) ? argv[2] : "plan";
+    char const fF = (argc > 3) ? char(argv[3][0] | 32) : 'f';
+    int const nrep = (argc > 4) ? std::atoi(argv[4]) : 1;
+    int const nsamp = (argc > 5) ? std::atoi(argv[5]) : 1;
+    int const lm = (argc > 6) ? std::atoi(argv[6]) : 16;
+    int const ln = (argc > 7) ? std::atoi(argv[7]) : lm;
+    bool const dbl = ('d' == fF || 'z' == fF);
+    char const prec = dbl ? 'z' : 'c';
+
+    std::string const text = slurp(path);
+    std::istringstream in(text);
+    std::string tag; long nY = 0, nA = 0, nX = 0;
+    in >> tag >> nY >> nA >> nX;
+    if (tag.empty() || tag[0] != '#' || nY < 1) { std::fprintf(stderr, "'%s' is not a plan file\n", path.c_str()); return 1; }
+    std::vector<uint32_t> starts, pairs;
+    long iY, iA, iX, beta, last = -1;
+    while (in >> iY >> iA >> iX >> beta) {
+        if (iY != last) { starts.push_back(uint32_t(pairs.size() / 2)); last = iY; }
+        pairs.push_back(uint32_t(iA)); pairs.push_back(uint32_t(iX));
+    }
+    starts.push_back(uint32_t(pairs.size() / 2));
+    if (long(starts.size()) != nY + 1) { std::fprintf(stderr, "plan file lists %zu Y blocks, header says %ld\n", starts.size() - 1, nY); return 1; }
+    size_t const nPairs = pairs.size() / 2;
+    std::printf("\n# bench_multi<%d,%d> on GPU !!!!\n", lm, ln);
+    std::printf("# Execute %d repetitions, sample %d times.\n", nrep, nsamp);
+
+    size_t const rb = dbl ? 8 : 4;
+    auto fill = [&](size_t n, int rows, int cols) {   // Re = cos(arg), Im = sin(arg), arg = running element index
+        std::vector<char> v(n * 2 * rows * cols * rb);
+        for (size_t b = 0; b < n; ++b)
+            for (int e = 0; e < rows * cols; ++e) {
+                double const arg = double(b * rows * cols + e);
+                size_t const re = (b * 2 + 0) * rows * cols + e, im = (b * 2 + 1) * rows * cols + e;
+                if (dbl) { ((double*)v.data())[re] = std::cos(arg); ((double*)v.data())[im] = std::sin(arg); }
+                else     { ((float*) v.data())[re] = float(std::cos(arg)); ((float*)v.data())[im] = float(std::sin(arg)); }
+            }
+        return v;
+    };
+    auto const A = fill(nA, lm, lm), X = fill(nX, lm, ln);
+    size_t const yBytes = size_t(nY) * 2 * lm * ln * rb;
+    void *dA, *dX, *dY; uint32_t *dS, *dP;
+    CHECK_HIP(hipMalloc(&dA, A.size())); CHECK_HIP(hipMalloc(&dX, X.size())); CHECK_HIP(hipMalloc(&dY, yBytes));
+    CHECK_HIP(hipMalloc((void**)&dS, starts.size() * 4)); CHECK_HIP(hipMalloc((void**)&dP, pairs.size() * 4));
+    CHECK_HIP(hipMemcpy(dA, A.data(), A.size(), hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(dX, X.data(), X.size(), hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemset(dY, 0, yBytes));
+    CHECK_HIP(hipMemcpy(dS, starts.data(), starts.size() * 4, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMemcpy(dP, pairs.data(), pairs.size() * 4, hipMemcpyHostToDevice));
+
+    tfqmrgpuHandle_t handle = nullptr;
+    CHECK_TFQ(tfqmrgpuCreateHandle(&handle));
+    CHECK_TFQ(tfqmrgpuExt_multiply(handle, prec, lm, ln, uint32_t(nY), dS, dP, dA, dX, dY));   // warm-up (module load)
+    CHECK_HIP(hipDeviceSynchronize());
+    std::vector<double> times;
+    double nflop = 0;
+    for (int s = 0; s < nsamp; ++s) {
+        double const t0 = now();
+        for (int r = 0; r < nrep; ++r) CHECK_TFQ(tfqmrgpuExt_multiply(handle, prec, lm, ln, uint32_t(nY), dS, dP, dA, dX, dY));
+        CHECK_HIP(hipDeviceSynchronize());
+        times.push_back(now() - t0);
+        nflop += double(nrep) * double(nPairs) * 8.0 * lm * lm * ln;
+    }
+    double tsum = 0, t2 = 0;
+    for (double t : times) { tsum += t; t2 += t * t; }
+    double const tavg = tsum / nsamp, tdev = std::sqrt(std::max(0.0, t2 / nsamp - tavg * tavg));
+    std::printf("# GPU needed %.3f seconds, %.6f +/- %.6f sec per sample\n", tsum, tavg, tdev);
+
+    // host re-computation in double: Y[iY] = sum_p A^T-stored[iA] * X[iX]
+    std::vector<char> Yg(yBytes);
+    CHECK_HIP(hipMemcpy(Yg.data(), dY, yBytes, hipMemcpyDeviceToHost));
+    auto get = [&](std::vector<char> const& v, size_t idx) { return dbl ? ((double const*)v.data())[idx] : double(((float const*)v.data())[idx]); };
+    double maxdev = 0;
+    size_t const PA = size_t(lm) * lm, PX = size_t(lm) * ln;
+    std::vector<double> yr(PX), yi(PX);
+    for (long y = 0; y < nY; ++y) {
+        std::fill(yr.begin(), yr.end(), 0.0); std::fill(yi.begin(), yi.end(), 0.0);
+        for (uint32_t q = starts[y]; q < starts[y + 1]; ++q) {
+            size_t const a0 = size_t(pairs[2 * q]) * 2 * PA, x0 = size_t(pairs[2 * q + 1]) * 2 * PX;
+            for (int k = 0; k < lm; ++k)
+                for (int i = 0; i < lm; ++i) {
+                    double const ar = get(A, a0 + k * lm + i), ai = get(A, a0 + PA + k * lm + i);   // A[k][i]: stored transposed
+                    for (int j = 0; j < ln; ++j) {
+                        double const xr = get(X, x0 + k * ln + j), xi = get(X, x0 + PX + k * ln + j);
+                        yr[i * ln + j] += ar * xr - ai * xi; yi[i * ln + j] += ar * xi + ai * xr;
+                    }
+                }
+        }
+        for (size_t e = 0; e < PX; ++e) {
+            maxdev = std::max(maxdev, std::abs(get(Yg, size_t(y) * 2 * PX + e) - yr[e]));
+            maxdev = std::max(maxdev, std::abs(get(Yg, size_t(y) * 2 * PX + PX + e) - yi[e]));
+        }
+    }
+    std::printf("# GPU maxdev %g\n", maxdev);
+    int rc = 0;
+    if (maxdev > 1e-4) { std::printf("# Warning! GPU result has large deviations (%g) for blockDim=%d x %d\n", maxdev, lm, ln); rc = 1; }
+    else {
+        char const ch = dbl ? 'F' : 'f';
+        std::printf("# GPU performed %.3f T%clop in %.3f seconds\n", nflop * 1e-12, ch, tsum);
+        std::printf("# GPU performance (lm,ln,tune)=(%3d,%3d,%d) is  %.1f G%clop/sec\n", lm, ln, 0, nflop * 1e-9 / tsum, ch);
+    }
+    CHECK_TFQ(tfqmrgpuDestroyHandle(handle));
+    for (void* p : {dA, dX, dY, (void*)dS, (void*)dP}) (void)hipFree(p);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// minimal reader for the <LinearProblem> files
+struct Element {
+    std::string name;
+    std::map<std::string, std::string> attr;
+    std::string text;
+    std::vector<Element> kids;
+    Element const* child(char const* n) const { for (auto const& k : kids) if (k.name == n) return &k; return nullptr; }
+    std::string get(char const* a, char const* dflt) const { auto it = attr.find(a); return it == attr.end() ? dflt : it->second; }
+};
+
+size_t parse_element(std::string const& s, size_t pos, Element& e) {   // pos at '<' of the start tag
+    size_t p = pos + 1;
+    while (p < s.size() && !std::isspace((unsigned char)s[p]) && s[p] != '>' && s[p] != '/') ++p;
+    e.name = s.substr(pos + 1, p - pos - 1);
+    for (;;) {                                                             // attributes
+        while (p < s.size() && std::isspace((unsigned char)s[p])) ++p;
+        if (p >= s.size()) return p;
+        if (s[p] == '/') return s.find('>', p) + 1;                        // <tag ... />
+        if (s[p] == '>') { ++p; break; }
+        size_t const eq = s.find('=', p);
+        std::string key = s.substr(p, eq - p);
+        while (!key.empty() && std::isspace((unsigned char)key.back())) key.pop_back();
+        size_t q0 = eq + 1;
+        while (std::isspace((unsigned char)s[q0])) ++q0;
+        char const quote = s[q0];
+        size_t const q1 = s.find(quote, q0 + 1);
+        e.attr[key] = s.substr(q0 + 1, q1 - q0 - 1);
+        p = q1 + 1;
+    }
+    for (;;) {                                                             // content
+        size_t const lt = s.find('<', p);
+        if (lt == std::string::npos) return s.size();
+        e.text.append(s, p, lt - p);
+        if (s.compare(lt, 4, "<!--") == 0) { p = s.find("-->", lt) + 3; continue; }
+        if (s[lt + 1] == '/') return s.find('>', lt) + 1;                  // end tag
+        Element k; p = parse_element(s, lt, k); e.kids.push_back(std::move(k));
+    }
+}
+
+template <typename T> std::vector<T> numbers(std::string const& text) {
+    std::vector<T> v; char const* p = text.c_str(); char* end;
+    for (;;) {
+        double const d = std::strtod(p, &end);
+        if (end == p) break;
+        v.push_back(T(d)); p = end;
+    }
+    return v;
+}
+
+struct Operator { std::vector<int32_t> rowPtr, colInd; std::vector<std::complex<double>> val; int rows = 0, cols = 0; bool hasData = false; };
+
+Operator read_operator(Element const& bsm) {
+    Operator o;
+    auto const* sm = bsm.child("SparseMatrix");
+    auto const* csr = sm ? sm->child("CompressedSparseRow") : nullptr;
+    if (!csr) { std::fprintf(stderr, "BlockSparseMatrix without CompressedSparseRow\n"); std::exit(1); }
+    if (auto const* n = csr->child("NonzerosPerRow")) {
+        auto const per = numbers<int64_t>(n->text);
+        o.rowPtr.assign(1, 0);
+        for (auto c : per) o.rowPtr.push_back(o.rowPtr.back() + int32_t(c));
+    } else if (auto const* r = csr->child("RowStart")) o.rowPtr = numbers<int32_t>(r->text);
+    if (auto const* c = csr->child("ColumnIndex")) o.colInd = numbers<int32_t>(c->text);
+    size_t const nnzb = o.colInd.size();
+    std::vector<int64_t> ind;
+    if (auto const* i = sm->child("Indirection")) ind = numbers<int64_t>(i->text);
+    if (auto const* dt = bsm.child("DataTensor")) {
+        double const scale = std::atof(dt->get("scale", "1").c_str());
+        bool const cplx = ((dt->get("type", "complex")[0] | 32) == 'c');
+        auto const dims = numbers<int64_t>(dt->get("dimensions", "0 0 0"));
+        o.rows = int(dims.size() > 1 ? dims[1] : 0); o.cols = int(dims.size() > 2 ? dims[2] : 0);
+        size_t const blk = size_t(o.rows) * o.cols;
+        o.val.assign(nnzb * blk, 0.0);
+        if (!dims.empty() && dims[0] > 0) {
+            auto const data = numbers<double>(dt->text);
+            for (size_t b = 0; b < nnzb; ++b) {
+                size_t const src = ind.empty() ? b : size_t(ind[b]);
+                for (size_t e = 0; e < blk; ++e)
+                    o.val[b * blk + e] = scale * (cplx ? std::complex<double>(data[(src * blk + e) * 2], data[(src * blk + e) * 2 + 1])
+                                                       : std::complex<double>(data[src * blk + e], 0.0));
+            }
+            o.hasData = true;
+        }
+    }
+    return o;
+}
+
+int bench_tfqmr(int argc, char** argv) {
+    std::string const path = (argc > 2) ? argv[2] : "problem";
+    char p0 = (argc > 3) ? char(argv[3][0] | 32) : 'z';
+    char const prec = ('d' == p0 || 'z' == p0) ? 'z' : 'c';
+    int const maxiter = (argc > 5) ? std::atoi(argv[5]) : 2000;
+    std::printf("\n# read file '%s' as input.\n", path.c_str());
+    std::string const text = slurp(path);
+    size_t pos = text.find("<LinearProblem");
+    if (pos == std::string::npos) { std::fprintf(stderr, "%s: no <LinearProblem> root\n", path.c_str()); return 1; }
+    Element root; parse_element(text, pos, root);
+    double const tol = std::atof(root.get("tolerance", "0").c_str());
+    std::printf("# found tolerance= %g\n", tol);
+    Operator A, B, X;
+    for (auto const& k : root.kids) if (k.name == "BlockSparseMatrix") {
+        char const id = k.get("id", "?")[0];
+        (id == 'A' ? A : id == 'B' ? B : X) = read_operator(k);
+    }
+    int const mb = int(A.rowPtr.size()) - 1, LM = A.rows, LN = B.cols;
+    std::printf("# requested precision= '%c' for LM= %d, LN= %d\n", prec, LM, LN);
+    std::printf("\n# nnzb for A=%zu, X=%zu, B=%zu\n", A.colInd.size(), X.colInd.size(), B.colInd.size());
+
+    tfqmrgpuHandle_t handle = nullptr; tfqmrgpuBsrsvPlan_t plan = nullptr;
+    CHECK_TFQ(tfqmrgpuCreateHandle(&handle));
+    CHECK_TFQ(tfqmrgpu_bsrsv_createPlan(handle, &plan, mb, A.rowPtr.data(), int(A.colInd.size()), A.colInd.data(),
+        X.rowPtr.data(), int(X.colInd.size()), X.colInd.data(), B.rowPtr.data(), int(B.colInd.size()), B.colInd.data(), 0, 0));
+    size_t nbytes = 0;
+    CHECK_TFQ(tfqmrgpu_bsrsv_bufferSize(handle, plan, LM, LM, LN, LN, prec, &nbytes));
+    std::printf("# use %.6f GByte GPU memory\n", nbytes * 1e-9);
+    void* buffer = nullptr;
+    CHECK_TFQ(tfqmrgpuCreateWorkspace(&buffer, nbytes, 'd'));
+    CHECK_TFQ(tfqmrgpu_bsrsv_setBuffer(handle, plan, buffer));
+    auto convert = [&](std::vector<std::complex<double>> const& v) {   // interleaved Re/Im in the plan's precision
+        std::vector<char> out(v.size() * 2 * (prec == 'z' ? 8 : 4));
+        for (size_t e = 0; e < v.size(); ++e) {
+            if (prec == 'z') { ((double*)out.data())[2 * e] = v[e].real(); ((double*)out.data())[2 * e + 1] = v[e].imag(); }
+            else             { ((float*) out.data())[2 * e] = float(v[e].real()); ((float*)out.data())[2 * e + 1] = float(v[e].imag()); }
+        }
+        return out;
+    };
+    auto const Ah = convert(A.val), Bh = convert(B.val);
+    CHECK_TFQ(tfqmrgpu_bsrsv_setMatrix(handle, plan, 'A', Ah.data(), prec, LM, LM, 'n', TFQMRGPU_LAYOUT_RIRIRIRI));
+    CHECK_TFQ(tfqmrgpu_bsrsv_setMatrix(handle, plan, 'B', Bh.data(), prec, LN, LM, 'n', TFQMRGPU_LAYOUT_RIRIRIRI));
+    CHECK_HIP(hipDeviceSynchronize());
+    double const t0 = now();
+    tfqmrgpuStatus_t const st = tfqmrgpu_bsrsv_solve(handle, plan, tol, maxiter);
+    CHECK_HIP(hipDeviceSynchronize());
+    double const dt = now() - t0;
+    tfqmrgpuPrintError(st);
+    std::vector<char> Xh(X.colInd.size() * size_t(LM) * LN * 2 * (prec == 'z' ? 8 : 4));
+    CHECK_TFQ(tfqmrgpu_bsrsv_getMatrix(handle, plan, 'X', Xh.data(), prec, LN, LM, 'n', TFQMRGPU_LAYOUT_RIRIRIRI));
+    double residual = 0, flops = 0, flops_all = 0; int32_t iterations = 0;
+    CHECK_TFQ(tfqmrgpu_bsrsv_getInfo(handle, plan, &residual, &iterations, &flops, &flops_all));
+    int rc = int(st);
+    if (X.hasData) {
+        double maxdev = 0, sum = 0, maxref = 0;
+        for (size_t e = 0; e < X.val.size(); ++e) {
+            double const xr = prec == 'z' ? ((double*)Xh.data())[2 * e] : ((float*)Xh.data())[2 * e];
+            double const xi = prec == 'z' ? ((double*)Xh.data())[2 * e + 1] : ((float*)Xh.data())[2 * e + 1];
+            double const d = std::abs(std::complex<double>(xr, xi) - X.val[e]);
+            maxdev = std::max(maxdev, d); sum += d; maxref = std::max(maxref, std::abs(X.val[e]));
+        }
+        if (maxref > 0) {
+            std::printf("# GPU maxdev %g avgdev %g\n", maxdev, sum / double(X.val.size()));
+            if (maxdev >= 1e-5) rc = 1;
+        }
+    }
+    std::printf("# GPU converged to %.1e in %d iterations\n", residual, int(iterations));
+    char const ch = (prec == 'z') ? 'F' : 'f';
+    std::printf("# GPU performed %.3f T%clop in %.3f seconds = %.3f T%clop/s\n", flops * 1e-12, ch, dt, flops * 1e-12 / std::max(dt, 1e-6), ch);
+    CHECK_TFQ(tfqmrgpu_bsrsv_destroyPlan(handle, plan));
+    CHECK_TFQ(tfqmrgpuDestroyWorkspace(buffer));
+    CHECK_TFQ(tfqmrgpuDestroyHandle(handle));
+    return rc;
+}
+
+} // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        std::printf("Usage:  %s  [tfQMR/multiply]  [file]  [float/double]  [#repetitions]  [#iterations]  [#blocksize]\n", argv[0]);
+        return 1;
+    }
+    return ('m' == argv[1][0]) ? bench_multi(argc, argv) : bench_tfqmr(argc, argv);
+}
