@@ -54,10 +54,28 @@ template <bool STREAM, typename T> __device__ inline void st_stream(T* p, T v) {
 
 template <int EPI> struct EpiPlanes { static constexpr int N = (EPI == EPI_XPAY_DOT) ? 2 : (EPI == EPI_AXPY_NRM_DOT) ? 3 : (EPI == EPI_RESIDUAL) ? 1 : 0; };
 
-// per-element epilogue; off = offset of the element's real part in an X-shaped vector, P = plane size
-template <typename R, int EPI, bool STREAM = true>
-__device__ inline void epilogue(SpmmArgs const& a, size_t off, int P, R yr, R yi, R sr, R si,
-                                uint32_t bq, int eoff, double* acc /* [planes] */)
+// per-element epilogue; off = offset of the element's real part in an X-shaped vector, P = plane size.
+// In two steps so that a kernel can request the operands (old v4|v5, v8, v3) before its block products and use
+// them behind: EpiElem::load, epilogue_apply; epilogue() is the two in a row.
+template <typename R, int EPI, bool STREAM>
+struct EpiElem {
+    R ur, ui, xr, xi; float wr, wi;
+    __device__ inline void load(SpmmArgs const& a, size_t off, int P) {
+        if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
+            R const* u = (R const*)a.e0;
+            ur = ld_stream<STREAM>(u + off); ui = ld_stream<STREAM>(u + off + P);
+            wr = ld_stream<STREAM>(a.v3 + off); wi = ld_stream<STREAM>(a.v3 + off + P);
+        }
+        if constexpr (EPI == EPI_XPAY_DOT) {
+            R const* v8 = (R const*)a.e1;
+            xr = ld_stream<STREAM>(v8 + off); xi = ld_stream<STREAM>(v8 + off + P);
+        }
+    }
+};
+
+template <typename R, int EPI, bool STREAM>
+__device__ inline void epilogue_apply(SpmmArgs const& a, size_t off, int P, R yr, R yi, R sr, R si,
+                                      EpiElem<R, EPI, STREAM> const& o, uint32_t bq, int eoff, double* acc /* [planes] */)
 {
     if constexpr (EPI == EPI_NONE) {
         st_stream<STREAM>((R*)a.Y + off, yr); st_stream<STREAM>((R*)a.Y + off + P, yi);
@@ -65,23 +83,20 @@ __device__ inline void epilogue(SpmmArgs const& a, size_t off, int P, R yr, R yi
         // v9 := A v6 (kept for the v5 update); v4 := v8 + beta v4; v4 := v9 + beta v4; pz += v3 . v4
         // (tfqmrgpu_core.hxx:196-202)
         st_stream<STREAM>((R*)a.Y + off, yr); st_stream<STREAM>((R*)a.Y + off + P, yi);
-        R* v4 = (R*)a.e0; R const* v8 = (R const*)a.e1;
-        R ur = ld_stream<STREAM>(v4 + off), ui = ld_stream<STREAM>(v4 + off + P);
-        R const xr = ld_stream<STREAM>(v8 + off), xi = ld_stream<STREAM>(v8 + off + P);
-        R tr = xr + sr * ur - si * ui, ti = xi + si * ur + sr * ui;
-        ur = yr + sr * tr - si * ti; ui = yi + si * tr + sr * ti;
+        R* v4 = (R*)a.e0;
+        R const tr = o.xr + sr * o.ur - si * o.ui, ti = o.xi + si * o.ur + sr * o.ui;
+        R const ur = yr + sr * tr - si * ti, ui = yi + si * tr + sr * ti;
         st_stream<STREAM>(v4 + off, ur); st_stream<STREAM>(v4 + off + P, ui);
-        double const wr = ld_stream<STREAM>(a.v3 + off), wi = ld_stream<STREAM>(a.v3 + off + P), dr = ur, di = ui;
+        double const wr = o.wr, wi = o.wi, dr = ur, di = ui;
         acc[0] += dr * wr - di * wi;
         acc[1] += dr * wi + di * wr;
     } else if constexpr (EPI == EPI_AXPY_NRM_DOT) {
         // v8 := A v6; v5 := alfa v8 + v5; pd += |v5|^2; pz += v3 . v5  (tfqmrgpu_core.hxx:224-228,189)
         st_stream<STREAM>((R*)a.Y + off, yr); st_stream<STREAM>((R*)a.Y + off + P, yi);
         R* v5 = (R*)a.e0;
-        R ur = ld_stream<STREAM>(v5 + off), ui = ld_stream<STREAM>(v5 + off + P);
-        R const nr = sr * yr - si * yi + ur, ni = si * yr + sr * yi + ui;
+        R const nr = sr * yr - si * yi + o.ur, ni = si * yr + sr * yi + o.ui;
         st_stream<STREAM>(v5 + off, nr); st_stream<STREAM>(v5 + off + P, ni);
-        double const wr = ld_stream<STREAM>(a.v3 + off), wi = ld_stream<STREAM>(a.v3 + off + P), dr = nr, di = ni;
+        double const wr = o.wr, wi = o.wi, dr = nr, di = ni;
         acc[0] += dr * wr - di * wi;
         acc[1] += dr * wi + di * wr;
         acc[2] += dr * dr + di * di;
@@ -94,6 +109,15 @@ __device__ inline void epilogue(SpmmArgs const& a, size_t off, int P, R yr, R yi
         double const dr = rr, di = ri;
         acc[0] += dr * dr + di * di;
     }
+}
+
+template <typename R, int EPI, bool STREAM = true>
+__device__ inline void epilogue(SpmmArgs const& a, size_t off, int P, R yr, R yi, R sr, R si,
+                                uint32_t bq, int eoff, double* acc /* [planes] */)
+{
+    EpiElem<R, EPI, STREAM> o;
+    o.load(a, off, P);
+    epilogue_apply<R, EPI, STREAM>(a, off, P, yr, yi, sr, si, o, bq, eoff, acc);
 }
 
 template <int EPI>
@@ -527,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at leas
 // A[c = (l%16)/8][k0 + l/16][(l%16)%8] and X[c = (l%16)/8][k0 + l/16][8 nt + (l%16)%8].
 // After the pair loop the tile goes through a wave-private LDS patch and comes back as one complex
 // element per lane:  Y = (Q00 - Q11) + i (Q01 + Q10),  lane l <-> element (row l/8, column l%8).
-template <typename R, int LM, int LN, int EPI>
+template <typename R, int LM, int LN, int EPI, bool PRE>
 __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
     if (gate_closed(a)) return;
     static_assert(LM == 4 || LM == 8, "[Re A; Im A] must fit the 16 rows of a tile");
@@ -568,6 +592,14 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = T4{0, 0, 0, 0};
         uint32_t const q0 = a.starts[y], q1 = a.starts[y + 1];
+        // the operands of this block's epilogue travel while its products are computed (PRE; TFQMRGPU_EPI_PREFETCH=0: behind them)
+        EpiElem<R, EPI, LN == 8> eo[PRE ? NT : 1];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                if ((LM == 8 || ei < LM) && (!RAGGED || nt * 8 + ej < LN))
+                    eo[nt].load(a, size_t(y) * 2 * P + ei * LN + nt * 8 + ej, P);
+        }
         auto fetch = [&](Ops& o, uint32_t q) {
             R const* Ab = A0 + size_t(a.pairs[2 * size_t(q)]) * 2 * LM * LM;
             R const* Xb = X0 + size_t(a.pairs[2 * size_t(q) + 1]) * 2 * P;
@@ -614,8 +646,10 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
             R const yi = tile[wave][er][ej + 8] + tile[wave][er + LM][ej];
             int const e = ei * LN + nt * 8 + ej;
             double accp[NPL > 0 ? NPL : 1] = {};
-            if ((LM == 8 || ei < LM) && (!RAGGED || nt * 8 + ej < LN))
-                epilogue<R, EPI, LN == 8>(a, size_t(y) * 2 * P + e, P, yr, yi, sr[nt], si[nt], bq, e, accp);   // LN == 8: the tile is one contiguous plane
+            if ((LM == 8 || ei < LM) && (!RAGGED || nt * 8 + ej < LN)) {   // STREAM for LN == 8: the tile is one contiguous plane
+                if constexpr (PRE) epilogue_apply<R, EPI, LN == 8>(a, size_t(y) * 2 * P + e, P, yr, yi, sr[nt], si[nt], eo[nt], bq, e, accp);
+                else epilogue<R, EPI, LN == 8>(a, size_t(y) * 2 * P + e, P, yr, yi, sr[nt], si[nt], bq, e, accp);
+            }
 #pragma unroll
             for (int p = 0; p < NPL; ++p) part[p][nt] += accp[p];
         }
@@ -758,7 +792,12 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
             if (pre && use_pre) k_spmm_mfma<R, LM, LN, EPI, pre, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
             else k_spmm_mfma<R, LM, LN, EPI, false, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
         }
-    } else if constexpr (kTile8<R, LM, LN>) k_spmm_mfma8<R, LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
+    } else if constexpr (kTile8<R, LM, LN>) {
+        constexpr bool pre8 = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
+        static int const use_pre8 = [] { auto v = std::getenv("TFQMRGPU_EPI_PREFETCH"); return v ? std::atoi(v) : 1; }();
+        if (pre8 && use_pre8) k_spmm_mfma8<R, LM, LN, EPI, pre8><<<dim3(nWG), dim3(256), 0, s>>>(a);
+        else k_spmm_mfma8<R, LM, LN, EPI, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
+    }
     else if constexpr (LM == 4) k_spmm_small4<R, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
     else k_spmm_direct<R, LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
 }
