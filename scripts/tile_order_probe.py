@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Does a 2-D tiled numbering of the block rows (so that a chunk of the solver is a tile, not a strip, of the grid)
 speed the fused multiplies up?  Same stencil problem with raster and with tiled row numbers.
-usage: python scripts/tile_order_probe.py [nx] [ncols] [tx] [ty]"""
+usage: python scripts/tile_order_probe.py [nx] [ncols] [tx] [ty] [LM] [LN]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -27,13 +27,15 @@ nx = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 ncols = int(sys.argv[2]) if len(sys.argv) > 2 else 48
 tx = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 ty = int(sys.argv[4]) if len(sys.argv) > 4 else 2
-pr = PR.stencil_2d(nx, nx, 16, 16, ncols, seed=7)
+LM = int(sys.argv[5]) if len(sys.argv) > 5 else 16
+LN = int(sys.argv[6]) if len(sys.argv) > 6 else LM
+pr = PR.stencil_2d(nx, nx, LM, LN, ncols, seed=7)
 y, x = np.divmod(np.arange(nx * nx), nx)
 key = ((y // ty) * (nx // tx) + (x // tx)) * (tx * ty) + (y % ty) * tx + (x % tx)
 tiled = permute_rows(pr, np.argsort(np.argsort(key)))
 for name, p in (("raster", pr), ("tiled %dx%d" % (tx, ty), tiled), ("raster", pr)):
     with T.Solver() as s:
-        s.create_plan(p); s.set_buffer(nbytes=s.buffer_size(16, 16, "z"))
+        s.create_plan(p); s.set_buffer(nbytes=s.buffer_size(LM, LN, "z"))
         s.set_matrix("A", p.A); s.set_matrix("B", p.B)
         s.set_profiling(True)
         tot = {}
