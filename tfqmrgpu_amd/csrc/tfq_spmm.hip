@@ -785,7 +785,7 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
         // P2 with either form).  Not in float: Im = P3 - P1 - P2 carries the rounding of the real parts, and the float
         // floor of the FD fixture (4.6e-5) moves above its threshold of 1e-4 (status 9 instead of 0).
         static int const use_m3 = [] { auto v = std::getenv("TFQMRGPU_3M"); return v ? std::atoi(v) : 1; }();
-        if (use_m3 && sizeof(R) == 8 && (LM / 16) * (LN / 16) >= 2) {
+        if (sizeof(R) == 8 && ((use_m3 && (LM / 16) * (LN / 16) >= 2) || use_m3 >= 2)) {   // TFQMRGPU_3M=2: 16 x 16 too (A/B runs)
             if (pre && use_pre) k_spmm_mfma<R, LM, LN, EPI, pre, true><<<dim3(nWG), dim3(256), 0, s>>>(a);
             else k_spmm_mfma<R, LM, LN, EPI, false, true><<<dim3(nWG), dim3(256), 0, s>>>(a);
         } else {
