@@ -147,6 +147,34 @@ static tfqmrgpuStatus_t reduce_over_ranks(Handle& h, DevPlan const& d, int off, 
 }
 
 // ---- the tfQMR driver -----------------------------------------------------------------------------
+// Optional roctx ranges around the two phases of a solve, named like the reference's NVTX ranges (tfqmrgpu_core.hxx:29,
+// 176-177,332; there compiled in with -DUSE_NVTX, here switched on with TFQMRGPU_ROCTX=1: libroctx64 is loaded on demand so
+// that the library carries no dependency on the tracing runtime).  rocprofv3 --marker-trace shows them.
+struct Roctx {
+    int (*push)(char const*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        auto const v = std::getenv("TFQMRGPU_ROCTX");
+        if (!v || 0 == std::atoi(v)) return;
+        // the rocprofiler-sdk flavour: it is the one rocprofv3 listens to (a run that loaded the legacy libroctx64 under
+        // rocprofv3 recorded no ranges and did not exit)
+        for (char const* name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so.1"}) {
+            if (void* lib = dlopen(name, RTLD_NOW | RTLD_LOCAL)) {
+                push = (decltype(push))dlsym(lib, "roctxRangePushA");
+                pop = (decltype(pop))dlsym(lib, "roctxRangePop");
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+struct RoctxRange {
+    Roctx const& r;
+    RoctxRange(Roctx const& r_, char const* name) : r(r_) { if (r.push) (void)r.push(name); }
+    ~RoctxRange() { if (r.pop) (void)r.pop(); }
+};
+static Roctx const& roctx() { static Roctx const r; return r; }
+
 // Algorithm = reference tfqmrgpu::solve (tfqmrgpu_core.hxx:179-306), restructured:
 //   dec35 | v6 | SpMM+v4+dot | dec34 | v5,nrm | decT | x,v7,v6,v7 | SpMM+v5+nrm+dot | decT | decide
 //   [ | x | SpMM residual | column records | decide ]   <- only does work when the bound asks for a probe
@@ -193,7 +221,8 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)
         ahead = std::min(DEPTH, std::max(1, int(vote[0])));
     }
-    vec_launch(VEC_SETUP, d, tol, maxIt, s);
+    { RoctxRange const range(roctx(), "tfQMR preparation"); vec_launch(VEC_SETUP, d, tol, maxIt, s); }
+    RoctxRange const range(roctx(), "tfQMR iterations");
 
     tfqmrgpuStatus_t fail = TFQMRGPU_STATUS_SUCCESS;
 
