@@ -178,3 +178,69 @@ def test_shard_columns_partition():
             seen_b += list(bb)
         assert first == len(cols)
         assert sorted(seen_x) == list(range(pr.nnzbX)) and sorted(seen_b) == list(range(pr.nnzbB))
+
+
+def _random_pattern_problem(rng):
+    """random ragged patterns: unsorted rows, duplicate entries, gaps in the column numbers of X, rows without
+    blocks, B on a random subset of X's blocks with every column covered, C or Fortran index offset"""
+    mb = int(rng.integers(1, 24))
+    ncol = int(rng.integers(1, 9))
+    colnames = np.sort(rng.choice(np.arange(0, 40), size=ncol, replace=False))   # gaps: empty columns in between
+    rpA, ciA, rpX, ciX = [0], [], [0], []
+    for r in range(mb):
+        n = int(rng.integers(0, min(mb, 6) + 1))
+        row = list(rng.choice(mb, size=n, replace=False))
+        if n and rng.random() < 0.2:
+            row.append(row[0])                                   # duplicate column in a row of A
+        ciA += row
+        rpA.append(len(ciA))
+        m = int(rng.integers(0, ncol + 1))
+        cols = list(colnames[rng.choice(ncol, size=m, replace=False)])
+        if m and rng.random() < 0.15:
+            cols.append(cols[-1])                                # duplicate block in a row of X
+        ciX += cols
+        rpX.append(len(ciX))
+    if not ciX:                                                  # X needs at least one block
+        ciX, rpX = [int(colnames[0])], [0] + [1] * mb
+    # B: the first block of every column of X, plus a random subset of further (row, column) positions
+    seen_col, rpB, ciB = set(), [0], []
+    for r in range(mb):
+        done = set()
+        for c in ciX[rpX[r]:rpX[r + 1]]:
+            if c in done:
+                continue
+            if c not in seen_col or rng.random() < 0.3:
+                ciB.append(c); seen_col.add(c); done.add(c)
+        rpB.append(len(ciB))
+    off = int(rng.integers(0, 2))
+    z = lambda n: np.zeros((n, 4, 4), complex)
+    return T.Problem(np.array(rpA) + off, np.array(ciA, dtype=np.int64) + off, z(len(ciA)), np.array(rpX) + off,
+                     np.array(ciX, dtype=np.int64) + off, np.array(rpB) + off, np.array(ciB, dtype=np.int64) + off, z(len(ciB)),
+                     None, 0.0, off)
+
+
+def test_create_plan_random_patterns_bit_exact(oracle):
+    """120 random ragged systems: the library's index analysis against the C restatement and, where it was built, against
+    the reference itself -- pairs, starts, subset, colindx, original_bsrColIndX and the status, bit for bit"""
+    rng = np.random.default_rng(20260)
+    ref = oracle.Reference() if oracle.have_ref() else None
+    nonempty = 0
+    for case in range(120):
+        pr = _random_pattern_problem(rng)
+        an = oracle.analyse(pr)
+        with T.Solver() as s:
+            st = _create(pr, s.handle, s.plan)
+            assert T.decode(st)[0] == T.decode(an["status"])[0], (case, st, an["status"])
+            if st == 0:
+                v = s.plan_view()
+                for k in PLAN_KEYS + ("original_bsrColIndX",):
+                    assert np.array_equal(v[k], an[k]), (case, k)
+                assert v["nCols"] == an["nCols"]
+                nonempty += (v["nPairs"] > 0)
+        if ref is not None:
+            r = ref.analyse(pr)
+            assert T.decode(r["status"])[0] == T.decode(an["status"])[0], case
+            if an["status"] == 0:
+                for k in PLAN_KEYS + ("original_bsrColIndX",):
+                    assert np.array_equal(r[k], an[k]), (case, k)
+    assert nonempty > 60
