@@ -427,3 +427,64 @@ def test_edge_rows_without_blocks(torch_cuda, oracle):
             torch.cuda.synchronize()
         got = dY.cpu().numpy()
         assert np.abs(got - want).max() < 1e-12 and np.all(got[[0, 2, 3, 5, 6, 7]] == 0)
+
+
+def _random_system(rng, LM, LN):
+    """random ragged system: A = strongly diagonally dominant random blocks on a random pattern (unsorted rows), X on a
+    random set of block columns with gaps in their numbers, ragged per row, B = a random subset of X's blocks that covers
+    every column, Fortran or C offsets"""
+    mb = int(rng.integers(2, 13))
+    ncol = int(rng.integers(1, 5))
+    colnames = np.sort(rng.choice(np.arange(0, 12), size=ncol, replace=False))
+    rpA, ciA, blocks = [0], [], []
+    for r in range(mb):
+        others = [c for c in rng.permutation(mb)[: int(rng.integers(0, 4))] if c != r]
+        row = list(rng.permutation([r] + others))
+        for c in row:
+            blk = (rng.uniform(-1, 1, (LM, LM)) + 1j * rng.uniform(-1, 1, (LM, LM))) / (LM * 4)
+            if c == r:
+                blk = blk + (2.0 + 0.5j) * np.eye(LM)
+            blocks.append(blk)
+        ciA += row
+        rpA.append(len(ciA))
+    rpX, ciX = [0], []
+    for r in range(mb):
+        m = int(rng.integers(0, ncol + 1))
+        ciX += list(colnames[rng.permutation(ncol)[:m]])
+        rpX.append(len(ciX))
+    for c in colnames:                                       # every column at least once
+        if c not in ciX:
+            r = int(rng.integers(0, mb))
+            ciX.insert(rpX[r + 1], int(c))
+            for q in range(r + 1, mb + 1):
+                rpX[q] += 1
+    seen, rpB, ciB = set(), [0], []
+    for r in range(mb):
+        for c in ciX[rpX[r]:rpX[r + 1]]:
+            if c not in seen or rng.random() < 0.4:
+                ciB.append(c); seen.add(c)
+        rpB.append(len(ciB))
+    B = rng.uniform(-1, 1, (len(ciB), LM, LN)) + 1j * rng.uniform(-1, 1, (len(ciB), LM, LN))
+    off = int(rng.integers(0, 2))
+    return T.Problem(np.array(rpA) + off, np.array(ciA, dtype=np.int64) + off, np.array(blocks), np.array(rpX) + off,
+                     np.array(ciX, dtype=np.int64) + off, np.array(rpB) + off, np.array(ciB, dtype=np.int64) + off, B, None, 1e-10, off)
+
+
+def test_random_ragged_systems(oracle):
+    """30 random systems over all block shapes: the GPU solution against the oracle's (same iteration count in double with
+    the reference's shadow vector) and against the dense LAPACK solution of the pattern-truncated system"""
+    rng = np.random.default_rng(424242)
+    for case in range(30):
+        LM, LN = SIZES[case % len(SIZES)]
+        prec = "z" if case % 3 else "c"
+        pr = _random_system(rng, LM, LN)
+        tol = 1e-10 if prec == "z" else 1e-4
+        st, X, info = T.solve_problem(pr, prec, threshold=tol, max_iterations=300, shadow_mode=T.SHADOW_GLIBC_RAND)
+        st0, X0, info0 = oracle.solve(pr, prec, threshold=tol, max_iterations=300)
+        assert st == st0 == 0, (case, LM, LN, prec, st, st0)
+        scale = np.abs(X0).max()
+        assert np.abs(X - X0).max() <= (_tol(prec) if prec == "z" else 1e-3) * scale, (case, LM, LN, prec)
+        if prec == "z":
+            assert info["iterations"] == info0["iterations"], (case, LM, LN)
+            Xd = PR.dense_reference_solution(pr)
+            assert np.abs(X - Xd).max() <= 1e-8 * np.abs(Xd).max(), (case, LM, LN)
