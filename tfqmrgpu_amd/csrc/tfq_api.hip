@@ -26,6 +26,8 @@ DevPlan resolve(Plan const& p) {
     d.LM = p.LM; d.LN = p.LN; d.dbl = ('z' == p.precision);
     d.nCols = p.nCols; d.nnzbX = p.nnzbX; d.nnzbB = p.nnzbB; d.nnzbA = p.nnzbA;
     d.nChunks = uint32_t(p.chunks.col.size());
+    static int const hashEnv = [] { auto v = std::getenv("TFQMRGPU_HASHV3"); return v ? std::atoi(v) : 1; }();
+    d.hashV3 = (p.v3IsHash && hashEnv) ? 1 : 0;   // TFQMRGPU_HASHV3=0: the multiply kernels read v3 also in hash mode
     d.x = at(p.wX); d.v4 = at(p.wV4); d.v5 = at(p.wV5); d.v6 = at(p.wV6); d.v7 = at(p.wV7);
     d.v8 = at(p.wV8); d.v9 = at(p.wV9); d.B = at(p.wB); d.A = at(p.wA); d.v3 = (float*)at(p.wV3);
     d.rho = at(p.wRho); d.alfa = at(p.wAlfa); d.beta = at(p.wBeta); d.c67 = at(p.wC67); d.eta = at(p.wEta);
@@ -530,7 +532,9 @@ tfqmrgpuStatus_t tfqmrgpu_bsrsv_setBuffer(tfqmrgpuHandle_t handle, tfqmrgpuBsrsv
         for (size_t i = 0; i < n; ++i) v3[i] = rng.next() * denom;
         st = transfer_blocks(*p, s, 0, false, d.v3, v3.data(), d.u2i, p->nnzbX, p->LM, p->LN, TFQMRGPU_LAYOUT_RRRRIIII, false, false);
         if (st) return st;
+        p->v3IsHash = false;
     } else {
+        p->v3IsHash = true;
         launch_shadow_hash(d, s);
         if (hipSuccess != hipGetLastError()) return TFQ_ERR(TFQMRGPU_STATUS_RANDOM_GEN_FAILED);
     }
@@ -745,6 +749,7 @@ tfqmrgpuStatus_t tfqmrgpuExt_setShadowVector(tfqmrgpuHandle_t handle, tfqmrgpuBs
     auto p = asPlan(plan); auto h = (Handle*)handle;
     if (!p || !h || !v3 || !p->buffer) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
     DevPlan const d = resolve(*p);
+    p->v3IsHash = false;
     return transfer_blocks(*p, (hipStream_t)h->stream, 0, false, d.v3, (void*)v3, d.u2i, p->nnzbX, p->LM, p->LN,
                            TFQMRGPU_LAYOUT_RRRRIIII, false, false);
 }

@@ -34,6 +34,7 @@ struct DevPlan {
     int LM, LN;
     bool dbl;
     uint32_t nCols, nnzbX, nnzbB, nnzbA, nChunks;
+    int hashV3;                                // v3 holds the counter-based hash below: kernels may recompute instead of reading it
     void *x, *v4, *v5, *v6, *v7, *v8, *v9, *B, *A;
     float* v3;
     void *rho, *alfa, *beta, *c67, *eta;       // [nCols][2][LN] real
@@ -49,6 +50,27 @@ struct DevPlan {
 };
 
 DevPlan resolve(Plan const& p);
+
+// ---- shadow vector -------------------------------------------------------------------------------
+// The reference fills v3 with cuRAND XORWOW uniforms on the GPU and rand()/RAND_MAX on the CPU
+// (tfqmrgpu_linalg.hxx:777-806); any positive random vector works.  Default here: a counter-based hash of
+// (original block column, block row, element) -> uniform (0, 1], so the value of an element does not depend on the
+// block order nor on how the columns are sharded over GPUs -- and the multiply kernels can recompute the values in
+// registers instead of reading S/2 (`z`) or S (`c`) bytes per fused launch.
+#ifdef __HIPCC__
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline uint64_t shadow_key(uint32_t origCol, uint32_t row) { return splitmix64((uint64_t(origCol) << 32) | uint64_t(row)) ^ 1234u; }
+// e: index of the element in the block, [Re | Im][LM][LN]
+__host__ __device__ inline float shadow_value(uint64_t key, uint32_t e) {
+    uint64_t const h = splitmix64(key + uint64_t(e) * 0xd1342543de82ef95ull);
+    return float((h >> 40) + 1) * (1.f / 16777216.f);   // 24 random bits -> (0, 1]
+}
+#endif
 
 enum { EPI_NONE = 0, EPI_XPAY_DOT = 1, EPI_AXPY_NRM_DOT = 2, EPI_RESIDUAL = 3 };
 

@@ -54,30 +54,16 @@ void launch_convert(int direction, bool dbl, void* native, void* stage, uint32_t
     else     k_convert<float ><<<dim3(nBlocks), dim3(256), 0, s>>>(direction, (float*)native, (float*)stage, u2n, firstUser, nR, nC, layout, trans, conj);
 }
 
-// ---- shadow vector ------------------------------------------------------------------------------
-// The reference fills v3 with cuRAND XORWOW uniforms on the GPU and rand()/RAND_MAX on the CPU
-// (tfqmrgpu_linalg.hxx:777-806); any positive random vector works.  Here: a counter-based hash of
-// (original block column, block row, element) -> uniform (0, 1], so the value of an element does not
-// depend on the block order nor on how the columns are sharded over GPUs.
-__device__ inline uint64_t splitmix64(uint64_t x) {
-    x += 0x9e3779b97f4a7c15ull;
-    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
-    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
-    return x ^ (x >> 31);
-}
-
+// ---- shadow vector: the counter-based hash of tfq_device.hpp written out (k_dot35 and the GLIBC/user modes read v3) ----
 __global__ __launch_bounds__(256) void k_shadow_hash(DevPlan d) {
     uint32_t const chunk = blockIdx.x;
     uint32_t const first = d.chunkFirst[chunk], last = d.chunkFirst[chunk + 1];
     uint64_t const col = uint64_t(uint32_t(d.origCol[d.chunkCol[chunk]]));
     int const E = 2 * d.LM * d.LN;
     for (uint32_t b = first; b < last; ++b) {
-        uint64_t const key = splitmix64((col << 32) | uint64_t(d.rowI[b])) ^ 1234u;
+        uint64_t const key = shadow_key(uint32_t(col), d.rowI[b]);
         float* v = d.v3 + size_t(b) * E;
-        for (int e = threadIdx.x; e < E; e += 256) {
-            uint64_t const h = splitmix64(key + uint64_t(e) * 0xd1342543de82ef95ull);
-            v[e] = float((h >> 40) + 1) * (1.f / 16777216.f);   // 24 random bits -> (0, 1]
-        }
+        for (int e = threadIdx.x; e < E; e += 256) v[e] = shadow_value(key, uint32_t(e));
     }
 }
 

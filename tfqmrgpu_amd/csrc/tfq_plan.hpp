@@ -87,6 +87,7 @@ struct Plan {
     void* ring = nullptr;              // pinned copies of the control block, one per in-flight iteration
     void* ringEvent[kDepth] = {};      // hipEvent_t behind each copy
     int shadowMode = TFQMRGPU_SHADOW_HASH;
+    bool v3IsHash = false;             // the buffer's v3 holds the counter-based hash (set by setBuffer, cleared by a user-supplied vector)
     bool haveB = false;
     // user-defined operator (tfqmrgpu_ext.h section 5): callback, and library-owned device scratch
     // [xu | yu | i2u | colindx in the caller's block order]

@@ -24,6 +24,7 @@
 // per-RHS scalars of the epilogue are uniform and the dot / norm contributions leave the work group
 // as one [LN] record (deterministic order).
 #include <cstdlib>
+#include <type_traits>
 
 #include "tfq_device.hpp"
 #include "tfq_vec.hpp"
@@ -43,6 +44,8 @@ struct SpmmArgs {
     void const* B; uint32_t const* bOfX;
     double* pz; double* pd;
     void const* Yext; uint32_t const* yPerm;   // k_spmm_direct only: take block y of the product from Yext[yPerm[y]]
+    int hashV3;                        // the shadow vector is the counter-based hash (tfq_device.hpp): recompute it, do not read it
+    int32_t const* origCol; uint32_t const* rowI;   // original block column per compressed column, block row per Y block
 };
 
 // data that a kernel touches once (epilogue vectors) moves non-temporally, so that the stream does not push the A and
@@ -355,7 +358,7 @@ struct Slice {
 };
 
 // the vectors an epilogue reads, for the NT neighbouring elements of one lane in one row
-template <typename R, int EPI, int NT>
+template <typename R, int EPI, int NT, bool HASH = false>
 struct EpiOps {
     static constexpr bool STREAM = (16 * NT * sizeof(R) >= 128);   // a lane group covers whole 128-byte lines
     R ur[NT], ui[NT], xr[NT], xi[NT];
@@ -363,7 +366,7 @@ struct EpiOps {
     __device__ inline void load(SpmmArgs const& a, size_t off, int P) {
         if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
             vload_stream<STREAM, R, NT>(ur, (R const*)a.e0 + off); vload_stream<STREAM, R, NT>(ui, (R const*)a.e0 + off + P);
-            vload_stream<STREAM, float, NT>(wr, a.v3 + off); vload_stream<STREAM, float, NT>(wi, a.v3 + off + P);
+            if constexpr (!HASH) { vload_stream<STREAM, float, NT>(wr, a.v3 + off); vload_stream<STREAM, float, NT>(wi, a.v3 + off + P); }   // HASH: recomputed in epilogue_row
         }
         if constexpr (EPI == EPI_XPAY_DOT) { vload_stream<STREAM, R, NT>(xr, (R const*)a.e1 + off); vload_stream<STREAM, R, NT>(xi, (R const*)a.e1 + off + P); }
     }
@@ -371,12 +374,12 @@ struct EpiOps {
 
 // epilogue for VW neighbouring elements at `off` (same arithmetic per element as epilogue<> above); the elements
 // are columns n0 .. n0 + VW - 1 of the NT columns of the lane (per-RHS scalars sr/si and partial sums are per column)
-template <typename R, int EPI, int VW, int NPL, int NT>
+template <typename R, int EPI, int VW, int NPL, int NT, bool HASH = false>
 __device__ inline void epilogue_row(SpmmArgs const& a, size_t off, int P, R const (&yr)[VW], R const (&yi)[VW],
-                                    R const (&sr)[NT], R const (&si)[NT], int n0, EpiOps<R, EPI, VW> const& o,
-                                    uint32_t bq, int eoff, double (&part)[NPL > 0 ? NPL : 1][NT])
+                                    R const (&sr)[NT], R const (&si)[NT], int n0, EpiOps<R, EPI, VW, HASH> const& o,
+                                    uint32_t bq, int eoff, double (&part)[NPL > 0 ? NPL : 1][NT], uint64_t key)
 {
-    if constexpr (EPI != EPI_RESIDUAL) { vstore_stream<EpiOps<R, EPI, VW>::STREAM, R, VW>((R*)a.Y + off, yr); vstore_stream<EpiOps<R, EPI, VW>::STREAM, R, VW>((R*)a.Y + off + P, yi); }
+    if constexpr (EPI != EPI_RESIDUAL) { vstore_stream<EpiOps<R, EPI, VW, HASH>::STREAM, R, VW>((R*)a.Y + off, yr); vstore_stream<EpiOps<R, EPI, VW, HASH>::STREAM, R, VW>((R*)a.Y + off + P, yi); }
     if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
         R nr[VW], ni[VW];
 #pragma unroll
@@ -388,12 +391,15 @@ __device__ inline void epilogue_row(SpmmArgs const& a, size_t off, int P, R cons
             } else {
                 nr[n] = cr * yr[n] - ci * yi[n] + o.ur[n]; ni[n] = ci * yr[n] + cr * yi[n] + o.ui[n];
             }
-            double const wr = o.wr[n], wi = o.wi[n], dr = nr[n], di = ni[n];
+            double wr, wi;   // the shadow vector: read, or recomputed from its hash (tfq_device.hpp)
+            if constexpr (HASH) { wr = shadow_value(key, uint32_t(eoff + n)); wi = shadow_value(key, uint32_t(P + eoff + n)); }
+            else { wr = o.wr[n]; wi = o.wi[n]; }
+            double const dr = nr[n], di = ni[n];
             part[0][n0 + n] += dr * wr - di * wi;
             part[1][n0 + n] += dr * wi + di * wr;
             if constexpr (EPI == EPI_AXPY_NRM_DOT) part[2][n0 + n] += dr * dr + di * di;
         }
-        vstore_stream<EpiOps<R, EPI, VW>::STREAM, R, VW>((R*)a.e0 + off, nr); vstore_stream<EpiOps<R, EPI, VW>::STREAM, R, VW>((R*)a.e0 + off + P, ni);
+        vstore_stream<EpiOps<R, EPI, VW, HASH>::STREAM, R, VW>((R*)a.e0 + off, nr); vstore_stream<EpiOps<R, EPI, VW, HASH>::STREAM, R, VW>((R*)a.e0 + off + P, ni);
     } else if constexpr (EPI == EPI_RESIDUAL) {
         R br[VW] = {}, bi[VW] = {};
         if (bq != 0xffffffffu) {
@@ -409,7 +415,7 @@ __device__ inline void epilogue_row(SpmmArgs const& a, size_t off, int P, R cons
     }
 }
 
-template <typename R, int LM, int LN, int EPI, bool PRE, bool M3>
+template <typename R, int LM, int LN, int EPI, bool PRE, bool M3, bool HASH>
 __global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at least 2 waves per SIMD: 256 VGPRs at most
     if (gate_closed(a)) return;
     static_assert(LM % 16 == 0 && LN % 16 == 0, "MFMA tiles are 16 x 16");
@@ -449,6 +455,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at leas
     for (uint32_t u = wave; u < nUnits; u += 4) {
         uint32_t const y = first + u / MU;
         int const i0 = int(u % MU) * 16 * MS;
+        uint64_t const key = HASH ? shadow_key(uint32_t(a.origCol[col]), a.rowI[y]) : 0;
         T4 cre[MS][NT], cim[MS][NT], cp3[M3 ? MS : 1][M3 ? NT : 1];   // M3: P1, P2, P3
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at leas
         Slice<R, MS, NT, KSL> o0, o1;
         if (nT > 0) fetch(o0, 0);
         if (nT > 1) fetch(o1, 1);
-        EpiOps<R, EPI, VW> ops[PRE ? MS * 4 * NG : 1];
+        EpiOps<R, EPI, VW, HASH> ops[PRE ? MS * 4 * NG : 1];
         if constexpr (PRE) {
 #pragma unroll
             for (int ms = 0; ms < MS; ++ms)
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at leas
                         } else { yr[n] = cre[ms][g * VW + n][r]; yi[n] = cim[ms][g * VW + n][r]; }
                     }
                     if constexpr (!PRE) ops[0].load(a, off, P);
-                    epilogue_row<R, EPI, VW, NPL, NT>(a, off, P, yr, yi, sr, si, g * VW, ops[PRE ? (ms * 4 + r) * NG + g : 0], bq, e, part);
+                    epilogue_row<R, EPI, VW, NPL, NT, HASH>(a, off, P, yr, yi, sr, si, g * VW, ops[PRE ? (ms * 4 + r) * NG + g : 0], bq, e, part, key);
                 }
     }
 
@@ -785,13 +792,22 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
         // P2 with either form).  Not in float: Im = P3 - P1 - P2 carries the rounding of the real parts, and the float
         // floor of the FD fixture (4.6e-5) moves above its threshold of 1e-4 (status 9 instead of 0).
         static int const use_m3 = [] { auto v = std::getenv("TFQMRGPU_3M"); return v ? std::atoi(v) : 1; }();
-        if (sizeof(R) == 8 && ((use_m3 && (LM / 16) * (LN / 16) >= 2) || use_m3 >= 2)) {   // TFQMRGPU_3M=2: 16 x 16 too (A/B runs)
-            if (pre && use_pre) k_spmm_mfma<R, LM, LN, EPI, pre, true><<<dim3(nWG), dim3(256), 0, s>>>(a);
-            else k_spmm_mfma<R, LM, LN, EPI, false, true><<<dim3(nWG), dim3(256), 0, s>>>(a);
-        } else {
-            if (pre && use_pre) k_spmm_mfma<R, LM, LN, EPI, pre, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
-            else k_spmm_mfma<R, LM, LN, EPI, false, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
-        }
+        // the shadow vector recomputed in registers where it is the library's hash and a lane owns one column (16 x 16): the
+        // fused kernels then read S/2 (`z`) or S (`c`) less (P2: 0.743 / 0.684 -> 0.719 / 0.673 ms); wider shapes and the
+        // tile kernels spill or lose (8 x 8 z +4 %, 32 x 32 c +15 %) and keep reading it
+        constexpr bool canHash = (LN == 16) && (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
+        bool const m3 = sizeof(R) == 8 && ((use_m3 && (LM / 16) * (LN / 16) >= 2) || use_m3 >= 2);   // TFQMRGPU_3M=2: 16 x 16 too (A/B runs)
+        bool const p = pre && use_pre;
+        auto go = [&](auto M3c, auto Hc) {
+            constexpr bool M3 = decltype(M3c)::value, H = decltype(Hc)::value;
+            if (p) k_spmm_mfma<R, LM, LN, EPI, pre, M3, H><<<dim3(nWG), dim3(256), 0, s>>>(a);
+            else k_spmm_mfma<R, LM, LN, EPI, false, M3, H><<<dim3(nWG), dim3(256), 0, s>>>(a);
+        };
+        using T = std::true_type; using F = std::false_type;
+        if constexpr (canHash) {
+            if (a.hashV3) { if (m3) go(T{}, T{}); else go(F{}, T{}); }
+            else { if (m3) go(T{}, F{}); else go(F{}, F{}); }
+        } else { if (m3) go(T{}, F{}); else go(F{}, F{}); }
     } else if constexpr (kTile8<R, LM, LN>) {
         constexpr bool pre8 = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
         static int const use_pre8 = [] { auto v = std::getenv("TFQMRGPU_EPI_PREFETCH"); return v ? std::atoi(v) : 1; }();
@@ -830,6 +846,7 @@ static SpmmArgs spmm_args(int epi, DevPlan const& d) {
     a.chunkFirst = d.chunkFirst; a.chunkCol = d.chunkCol; a.CH = 0;
     a.order = d.order;
     a.ctl = d.ctl; a.v3 = d.v3; a.B = d.B; a.bOfX = d.bOfX; a.pz = d.pz; a.pd = d.pd;
+    a.hashV3 = d.hashV3; a.origCol = d.origCol; a.rowI = d.rowI;
     switch (epi) {
     case EPI_XPAY_DOT:     a.X = d.v6; a.Y = d.v9; a.e0 = d.v4; a.e1 = d.v8; a.sc = d.beta; a.gate = 1; break;
     case EPI_AXPY_NRM_DOT: a.X = d.v6; a.Y = d.v8; a.e0 = d.v5; a.sc = d.alfa; a.gate = 1; break;
