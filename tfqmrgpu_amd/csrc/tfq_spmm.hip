@@ -794,7 +794,9 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
         static int const use_m3 = [] { auto v = std::getenv("TFQMRGPU_3M"); return v ? std::atoi(v) : 1; }();
         // the shadow vector recomputed in registers where it is the library's hash and a lane owns one column (16 x 16): the
         // fused kernels then read S/2 (`z`) or S (`c`) less (P2: 0.743 / 0.684 -> 0.719 / 0.673 ms); wider shapes and the
-        // tile kernels spill or lose (8 x 8 z +4 %, 32 x 32 c +15 %) and keep reading it
+        // tile kernels lose and keep reading it (measured with the hash everywhere: 8 x 8 z +4 %, 32 x 32 c fused +19 %, 16 x 64 c
+        // iteration +18 %, 32 x 64 c +41 %: more registers, and the hash competes with the epilogue for the vector ALU;
+        // 16 x 32 z and 64 x 64 z would gain 1 %)
         constexpr bool canHash = (LN == 16) && (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
         bool const m3 = sizeof(R) == 8 && ((use_m3 && (LM / 16) * (LN / 16) >= 2) || use_m3 >= 2);   // TFQMRGPU_3M=2: 16 x 16 too (A/B runs)
         bool const p = pre && use_pre;
