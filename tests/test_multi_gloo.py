@@ -27,7 +27,11 @@ def test_sharded_solve_equals_single_rank(oracle, tmp_path, world, name, tol):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "_gloo_worker.py"), out, name, repr(tol)]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    for attempt in range(3):   # the free port can be taken again before torchrun listens on it: a rendezvous error, nothing has run yet
+        cmd[cmd.index("--master-port") + 1] = str(_free_port())
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
+            break
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     g = np.load(out)
     pr = load_problem(name)
