@@ -266,7 +266,7 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
         //  reaches 0.77 ms, so A re-reads are not what bounds it any more.)
         auto envu = [](char const* name, uint32_t dflt) { auto v = std::getenv(name); return v ? uint32_t(std::atoi(v)) : dflt; };
         uint32_t const n = uint32_t(c.col.size());
-        uint32_t const mode = envu("TFQMRGPU_ORDER", 1), G = std::max(1u, envu("TFQMRGPU_ORDER_G", 8));
+        uint32_t const mode = envu("TFQMRGPU_ORDER", 1), G = std::max(1u, envu("TFQMRGPU_ORDER_G", 4));   // 8 until the epilogue streams went non-temporal / the shadow vector stopped being read: now 4 (P2 iteration 2.649 -> 2.626 ms, 8x8 z 2.819 -> 2.792, 2: 2.655)
         uint32_t const BM = std::max(1u, envu("TFQMRGPU_ORDER_BANDMULT", 1));   // bands of BM*CH block rows
         std::vector<uint32_t> sorted(n);
         std::iota(sorted.begin(), sorted.end(), 0u);
