@@ -7,14 +7,15 @@
 // complex arithmetic on split Re/Im planes, A blocks stored transposed ([k][i]), accumulation in the
 // storage precision.  Flop count nPairs*8*LM*LM*LN (tfqmrgpu_blocksparse.hxx:198).
 //
-// Two implementations:
+// Four implementations:
 //  * k_spmm_mfma : LM and LN multiples of 16.  One wavefront owns a 16 x LN strip of one Y block
 //    and keeps it in MFMA accumulators (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32).  The
 //    native layouts ARE the MFMA operand layouts: lane l feeds A[k0 + l/16][i0 + l%16] and
 //    X[k0 + l/16][columns of lane l%16], i.e. four consecutive rows per load instruction, so operands go
 //    global -> VGPR fully coalesced with no LDS transpose.  With several 16-column tiles per strip a lane
 //    owns NEIGHBOURING columns (ColMap below) and moves them as one 16-byte access.  4 real MFMA chains
-//    per complex product (-Im(A) is formed once per operand).
+//    per complex product (-Im(A) is formed once per operand), 3 in double above 16 x 16 (Slice::mma3); the 16 x 16
+//    instances recompute the shadow vector from its hash instead of reading it (HASH).
 //  * k_spmm_mfma8 : LM == 8 (and 4 x 32 z): [Re A; Im A] x [Re X | Im X] fills one 16 x 16 tile per 8 block columns (LN = 9,
 //    10: the last tile is masked; LM == 4: half of the rows are empty -- the matrix pipe is idle in these HBM-bound shapes).
 //  * k_spmm_small4 : the other 4-row shapes: one lane per element, operands once per thread group through LDS.
