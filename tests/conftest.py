@@ -19,7 +19,8 @@ def _build_once():
     import __graft_entry__ as g
     lib = os.path.join(ROOT, "tfqmrgpu_amd", "lib", "libtfQMRgpu.so")
     orc = os.path.join(ROOT, "oracle", "liboracle.so")
-    if not (os.path.exists(lib) and os.path.exists(orc)):
+    exe = os.path.join(ROOT, "tfqmrgpu_amd", "lib", "bench_tfqmrgpu")
+    if not (os.path.exists(lib) and os.path.exists(orc) and os.path.exists(exe)):
         g.build()
 
 
