@@ -4,11 +4,13 @@
 //
 //   bench_tfqmrgpu multi <planfile> [precision=f] [nrep=1] [nsamp=1] [lm=16] [ln=lm]
 //       plan file `#nnzb_for_Y_A_X= nY nA nX` + lines `iY iA iX beta` (bench_tfqmrgpu.cu:456-498), cos/sin fill
-//       (:274-287), host re-computation check maxdev <= 1e-4 (:349-420).  A `.gz` file is read through `gzip -dc`.
+//       (:274-287), host re-computation check maxdev <= 1e-4 (:349-420).  A `.gz` file is read with zlib.
 //   bench_tfqmrgpu tfQMR <problem.xml> [precision=z] [nrep=1] [MaxIter=2000]
 //       solves the <LinearProblem> (schema of tfqmrgpu_example_xml_reader.hxx:125-292) through createPlan ->
 //       bufferSize -> setBuffer -> setMatrix -> solve -> getInfo -> getMatrix and compares with the stored X if any
 //       (:178-205).  Blocks of the XML are row-major; transposition flag 'n' (see DESIGN.md on the reference's 't').
+//   bench_tfqmrgpu read <problem.xml>
+//       parses the file with the reader below and prints what it found (no GPU call; used by tests/test_fd_generator.py).
 // The XML reader below handles exactly that schema (elements with attributes and whitespace-separated numbers);
 // it is this program's own, the reference uses RapidXML.
 #include <algorithm>
@@ -26,6 +28,7 @@
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
+#include <zlib.h>
 
 #include "tfqmrgpu.h"
 #include "tfqmrgpu_ext.h"
@@ -40,19 +43,14 @@ double now() { return std::chrono::duration<double>(std::chrono::steady_clock::n
     tfqmrgpuPrintError(s_); std::fprintf(stderr, "%s:%d %s failed with status %d\n", __FILE__, __LINE__, #call, int(s_)); std::exit(2); } } while (0)
 
 std::string slurp(std::string const& path) {
-    if (path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0) {
-        std::string const cmd = "gzip -dc '" + path + "'";
-        FILE* p = popen(cmd.c_str(), "r");
-        if (!p) { std::fprintf(stderr, "cannot run %s\n", cmd.c_str()); std::exit(1); }
-        std::string s; char buf[1 << 16]; size_t n;
-        while ((n = fread(buf, 1, sizeof buf, p)) > 0) s.append(buf, n);
-        pclose(p);
-        return s;
-    }
-    std::ifstream f(path, std::ios::binary);
+    // gzopen reads plain files as well as gzip streams (no shell, no sub-process)
+    gzFile f = gzopen(path.c_str(), "rb");
     if (!f) { std::fprintf(stderr, "cannot open '%s'\n", path.c_str()); std::exit(1); }
-    std::ostringstream ss; ss << f.rdbuf();
-    return ss.str();
+    std::string s; char buf[1 << 16]; int n;
+    while ((n = gzread(f, buf, sizeof buf)) > 0) s.append(buf, size_t(n));
+    if (n < 0) { std::fprintf(stderr, "error while reading '%s'\n", path.c_str()); std::exit(1); }
+    gzclose(f);
+    return s;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -75,6 +73,12 @@ int bench_multi(int argc, char** argv) {
     std::vector<uint32_t> starts, pairs;
     long iY, iA, iX, beta, last = -1;
     while (in >> iY >> iA >> iX >> beta) {
+        // the lists go to the device as they are: refuse what would index outside of A or X there (Y blocks are numbered by
+        // group, a group = run of equal iY, as in the reference: the reordered plan file's iY values do not ascend)
+        if (iA < 0 || iA >= nA || iX < 0 || iX >= nX) {
+            std::fprintf(stderr, "'%s': line `%ld %ld %ld %ld` is out of range (nA %ld nX %ld)\n", path.c_str(), iY, iA, iX, beta, nA, nX);
+            return 1;
+        }
         if (iY != last) { starts.push_back(uint32_t(pairs.size() / 2)); last = iY; }
         pairs.push_back(uint32_t(iA)); pairs.push_back(uint32_t(iX));
     }
@@ -250,23 +254,50 @@ Operator read_operator(Element const& bsm) {
     return o;
 }
 
+struct ProblemFile { double tol = 0; Operator A, B, X; };
+
+bool read_problem(std::string const& path, ProblemFile& pf) {
+    std::string const text = slurp(path);
+    size_t const pos = text.find("<LinearProblem");
+    if (pos == std::string::npos) { std::fprintf(stderr, "%s: no <LinearProblem> root\n", path.c_str()); return false; }
+    Element root; parse_element(text, pos, root);
+    pf.tol = std::atof(root.get("tolerance", "0").c_str());
+    std::printf("# found tolerance= %g\n", pf.tol);
+    for (auto const& k : root.kids) if (k.name == "BlockSparseMatrix") {
+        char const id = k.get("id", "?")[0];
+        (id == 'A' ? pf.A : id == 'B' ? pf.B : pf.X) = read_operator(k);
+    }
+    return true;
+}
+
+// what the reader found, one line per operator; the checksum weighs every value with its position (1-based, flat over
+// [block][row][col]) so that a transposed block or a wrong indirection shows
+int bench_read(int argc, char** argv) {
+    ProblemFile pf;
+    if (argc < 3 || !read_problem(argv[2], pf)) return 1;
+    for (auto const* o : {&pf.A, &pf.B, &pf.X}) {
+        std::complex<double> sum = 0;
+        for (size_t e = 0; e < o->val.size(); ++e) sum += o->val[e] * double(e + 1);
+        std::printf("# operator %c rows %d nnzb %zu block %d x %d rowPtr [", o == &pf.A ? 'A' : o == &pf.B ? 'B' : 'X',
+                    int(o->rowPtr.size()) - 1, o->colInd.size(), o->rows, o->cols);
+        for (auto v : o->rowPtr) std::printf(" %d", v);
+        std::printf(" ] colInd [");
+        for (auto v : o->colInd) std::printf(" %d", v);
+        std::printf(" ] checksum %.17g %.17g\n", sum.real(), sum.imag());
+    }
+    return 0;
+}
+
 int bench_tfqmr(int argc, char** argv) {
     std::string const path = (argc > 2) ? argv[2] : "problem";
     char p0 = (argc > 3) ? char(argv[3][0] | 32) : 'z';
     char const prec = ('d' == p0 || 'z' == p0) ? 'z' : 'c';
     int const maxiter = (argc > 5) ? std::atoi(argv[5]) : 2000;
     std::printf("\n# read file '%s' as input.\n", path.c_str());
-    std::string const text = slurp(path);
-    size_t pos = text.find("<LinearProblem");
-    if (pos == std::string::npos) { std::fprintf(stderr, "%s: no <LinearProblem> root\n", path.c_str()); return 1; }
-    Element root; parse_element(text, pos, root);
-    double const tol = std::atof(root.get("tolerance", "0").c_str());
-    std::printf("# found tolerance= %g\n", tol);
-    Operator A, B, X;
-    for (auto const& k : root.kids) if (k.name == "BlockSparseMatrix") {
-        char const id = k.get("id", "?")[0];
-        (id == 'A' ? A : id == 'B' ? B : X) = read_operator(k);
-    }
+    ProblemFile pf;
+    if (!read_problem(path, pf)) return 1;
+    double const tol = pf.tol;
+    Operator const &A = pf.A, &B = pf.B, &X = pf.X;
     int const mb = int(A.rowPtr.size()) - 1, LM = A.rows, LN = B.cols;
     std::printf("# requested precision= '%c' for LM= %d, LN= %d\n", prec, LM, LN);
     std::printf("\n# nnzb for A=%zu, X=%zu, B=%zu\n", A.colInd.size(), X.colInd.size(), B.colInd.size());
@@ -332,5 +363,6 @@ int main(int argc, char** argv) {
         std::printf("Usage:  %s  [tfQMR/multiply]  [file]  [float/double]  [#repetitions]  [#iterations]  [#blocksize]\n", argv[0]);
         return 1;
     }
+    if ('r' == argv[1][0]) return bench_read(argc, argv);
     return ('m' == argv[1][0]) ? bench_multi(argc, argv) : bench_tfqmr(argc, argv);
 }
