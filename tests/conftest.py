@@ -39,6 +39,12 @@ SYNTHETIC = {
 ALL_NAMES = FD_NAMES + list(SYNTHETIC)
 
 
+def torchrun(world):
+    """one node, `world` ranks; --standalone lets the launcher pick a free rendezvous port itself (no probe-and-hope)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+            "--nproc-per-node", str(world)]
+
+
 def load_problem(name):
     if name in SYNTHETIC:
         return SYNTHETIC[name]()

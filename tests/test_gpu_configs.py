@@ -1,0 +1,122 @@
+"""BASELINE.json configurations 3, 4 and 5 at their full single-GPU sizes, through size-independent properties
+(the CPU oracle needs minutes to hours for these), and small instances of the same generators against the oracle.
+
+Properties checked on the device (all through the C-ABI: tfqmrgpu_bsrsv_* for the solve, tfqmrgpuExt_multiply --
+itself pinned to the oracle in test_gpu_parity.py -- for the check):
+  * the returned X satisfies A*X == B on the pattern: max_rhs |A x - b| / |b|, recomputed from the downloaded X,
+    is below the threshold AND equals the residual the solver reports (tfqmrgpu_core.hxx:263-298) to 1e-6;
+  * the multiply is linear: A(2.5 X + Z) == 2.5 A X + A Z to rounding.
+Needs an MI355X (`pytest -m gpu`)."""
+import numpy as np
+import pytest
+
+import tfqmrgpu_amd as T
+from tfqmrgpu_amd import problems as PR
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_solution_on_device(torch, oracle, pr, prec, X, info, tol):
+    real = torch.float64 if prec == "z" else torch.float32
+    an = oracle.analyse(pr)
+    assert an["status"] == 0
+    At = torch.from_numpy(pr.A).cuda().transpose(1, 2)                    # native A[k][i] = A[i][k]
+    An = torch.stack([At.real, At.imag], dim=1).to(real).contiguous()
+    Xc = torch.from_numpy(X).cuda()
+    Xn = torch.stack([Xc.real, Xc.imag], dim=1).to(real).contiguous()
+    del At, Xc
+    dS = torch.from_numpy(an["starts"].view(np.int32)).cuda()
+    dP = torch.from_numpy(an["pairs"].view(np.int32)).cuda()
+    Y = torch.zeros_like(Xn)
+    with T.Solver() as s:
+        def mult(x, y):
+            assert T.lib.tfqmrgpuExt_multiply(s.handle, prec.encode(), pr.LM, pr.LN, pr.nnzbX, dS.data_ptr(), dP.data_ptr(),
+                                              An.data_ptr(), x.data_ptr(), y.data_ptr()) == 0
+            torch.cuda.synchronize()
+        mult(Xn, Y)
+        Bc = torch.from_numpy(pr.B).cuda()
+        Bn = torch.stack([Bc.real, Bc.imag], dim=1).to(real)
+        sub = torch.from_numpy(an["subset"].astype(np.int64)).cuda()
+        col = torch.from_numpy(an["colindx"].astype(np.int64)).cuda()
+        R = Y.clone()
+        R[sub] -= Bn
+        res2 = torch.zeros((an["nCols"], pr.LN), dtype=torch.float64, device="cuda")
+        res2.index_add_(0, col, (R.double() ** 2).sum(dim=(1, 2)))
+        b2 = torch.zeros_like(res2)
+        b2.index_add_(0, col[sub], (Bn.double() ** 2).sum(dim=(1, 2)))
+        worst = float(torch.sqrt((res2 / b2).max()).item())
+        assert worst <= tol, worst
+        # the solver's own figure is computed in the storage precision with its own summation order
+        assert worst == pytest.approx(info["residual"], rel=1e-6 if prec == "z" else 2e-2)
+        del R, Bc
+        Z = torch.randn_like(Xn)
+        Y2, Y3 = torch.zeros_like(Xn), torch.zeros_like(Xn)
+        mult(Z, Y2)
+        mult(2.5 * Xn + Z, Y3)
+        eps = 1e-11 if prec == "z" else 1e-3
+        assert (Y3 - (2.5 * Y + Y2)).abs().max().item() <= eps * Y3.abs().max().item()
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "the gpu tests need a GPU; there is no CPU fallback"
+    torch.cuda.set_device(0)
+    return torch
+
+
+def test_config3_small_against_the_oracle(oracle):
+    # the generator of BASELINE config 3 (13-point block stencil, 32x32 complex<float>, 2 block columns = 64 RHS) at 8 x 8 rows
+    pr = PR.stencil_2d(8, 8, 32, 32, 2, seed=3, points=13)
+    v3 = T.hash_shadow_vector(pr).reshape(-1)
+    for prec, tol, xtol in (("c", 1e-4, 1e-3), ("z", 1e-9, 1e-7)):
+        st, X, info = T.solve_problem(pr, prec, threshold=tol, max_iterations=200)
+        st0, X0, info0 = oracle.solve(pr, prec, threshold=tol, max_iterations=200, v3=v3)
+        assert st == st0 == 0
+        assert abs(info["iterations"] - info0["iterations"]) <= (0 if prec == "z" else 1)
+        assert info["residual"] <= tol and np.abs(X - X0).max() <= xtol * np.abs(X0).max()
+        if prec == "z":
+            assert np.allclose(info["bound_history"], info0["bound_history"], rtol=1e-6, atol=0)
+
+
+def test_config3_full_size(torch_cuda, oracle):
+    # BASELINE config 3: 32x32 complex<float>, 4096 block rows, 51 456 nonzero A blocks (~50k), 64 right-hand sides,
+    # threshold 1e-4 (the float floor) -- what `bench.py --workload stencil3d_32x32_c` times
+    pr = PR.stencil_2d(64, 64, 32, 32, 2, seed=3, points=13)
+    assert (pr.mb, pr.nnzbX, pr.LM, pr.LN) == (4096, 8192, 32, 32) and 48000 <= pr.nnzbA <= 53248
+    st, X, info = T.solve_problem(pr, "c", threshold=1e-4, max_iterations=300)
+    assert st == 0 and info["residual"] <= 1e-4
+    _check_solution_on_device(torch_cuda, oracle, pr, "c", X, info, 1e-4)
+
+
+def test_config4_shard_of_one_gpu(torch_cuda, oracle):
+    # BASELINE config 4: 16x16 complex<double>, 128 x 128 block rows, 256 block columns over 8 GPUs -> 32 columns
+    # (512 right-hand sides, 524 288 X blocks, 2.1 GB per vector, 16.5 GB buffer) on this GPU; the RCCL stopping test
+    # with one rank (the 8-rank run is the driver's `bench.py --gpus 8 --workload cfg4`)
+    pr = PR.stencil_2d(128, 128, 16, 16, 32, seed=7)
+    assert (pr.mb, pr.nnzbA, pr.nnzbX, pr.nnzbB) == (16384, 81408, 524288, 32)
+    import ctypes as C
+    with T.Solver() as s:
+        s.create_plan(pr)
+        nbytes = s.buffer_size(16, 16, "z")
+        assert 15e9 < nbytes < 19e9
+        s.set_buffer(nbytes=nbytes)
+        s.set_matrix("A", pr.A)
+        s.set_matrix("B", pr.B)
+        uid = (C.c_char * 128)()
+        assert T.lib.tfqmrgpuExt_commUniqueId(uid) == 0 and T.lib.tfqmrgpuExt_commInit(s.handle, 1, 0, uid) == 0
+        st = s.solve(1e-9, 300)
+        info = s.get_info()
+        X = s.get_matrix()
+        assert T.lib.tfqmrgpuExt_commDestroy(s.handle) == 0
+    assert st == 0 and info["residual"] <= 1e-9
+    _check_solution_on_device(torch_cuda, oracle, pr, "z", X, info, 1e-9)
+
+
+def test_config5_one_gpu(torch_cuda, oracle):
+    # BASELINE config 5: 8x8 complex<double>, 5-point block stencil (~5 nonzero blocks per row), 8 block columns,
+    # 256 x 256 block rows (bench.py --workload stencil2d_8x8_z)
+    pr = PR.stencil_2d(256, 256, 8, 8, 8, seed=5)
+    st, X, info = T.solve_problem(pr, "z", threshold=1e-9, max_iterations=300)
+    assert st == 0 and info["residual"] <= 1e-9
+    _check_solution_on_device(torch_cuda, oracle, pr, "z", X, info, 1e-9)

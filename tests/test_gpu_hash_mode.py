@@ -1,0 +1,124 @@
+"""The DEFAULT shadow vector (counter-based hash) is what bench.py times: for 16 x 16 blocks the fused multiply kernels
+do not even read it, they recompute it in registers (k_spmm_mfma<..., HASH = true>, tfq_spmm.hip).  These tests pin
+that variant to the CPU oracle the same way the glibc-mode tests pin the other one: the oracle is fed with the very
+same vector (numpy restatement of tfq_device.hpp: shadow_key / shadow_value) and must take the same iterations
+with the same bound history (reference algorithm: tfqmrgpu_core.hxx:189-304).  Needs an MI355X (`pytest -m gpu`)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import tfqmrgpu_amd as T
+from conftest import ROOT, load_problem, offset1
+from tfqmrgpu_amd import problems as PR
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "fd_16x16_2d": lambda: load_problem("fd_16x16_2d"),
+    "fd_16x16_small": lambda: load_problem("fd_16x16_small"),
+    "fd_8x8_3d": lambda: load_problem("fd_8x8_3d"),
+    "fd_4x4_2d": lambda: load_problem("fd_4x4_2d"),
+    "dense_random": lambda: load_problem("dense_random"),
+    "stencil_8x8": lambda: load_problem("stencil_8x8"),
+    "stencil_8x32": lambda: load_problem("stencil_8x32"),
+    "st16x16": lambda: PR.stencil_2d(12, 12, 16, 16, 4, seed=7),          # the bench kernels' shape, 4 block columns
+    "st16x16_ragged": lambda: PR.stencil_2d(9, 7, 16, 16, 3, seed=9, radius=3.3),
+    "st32x32": lambda: PR.stencil_2d(6, 6, 32, 32, 2, seed=3),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_shadow_vector_is_the_documented_hash(name):
+    pr = CASES[name]()
+    for p in (pr, offset1(pr)):                       # Fortran indices must give the same vector (original column - offset)
+        for prec in "zc":
+            with T.Solver() as s:
+                s.create_plan(p)
+                s.set_buffer(nbytes=s.buffer_size(p.LM, p.LN, prec))
+                got = s.get_shadow_vector()
+            want = T.hash_shadow_vector(p)
+            assert got.dtype == want.dtype == np.float32 and np.array_equal(got, want), (name, prec)
+            assert want.min() > 0 and want.max() <= 1
+
+
+# Observed on MI355X (scripts/parity_report.py, profiles/r02_parity_report.txt): complex<double> trajectories of the HIP
+# path and of the oracle agree to HIST_RTOL over the whole bound history (MFMA summation order and FMA contraction
+# against the oracle's plain loops), final residuals to RES_RTOL; written per fixture as 2 x the observed deviation.
+Z_TOL = {   # name: (history rtol, residual rtol)
+    "fd_16x16_2d": (1e-6, 1e-6), "fd_16x16_small": (1e-6, 1e-6), "dense_random": (1e-6, 1e-6), "stencil_8x8": (1e-6, 1e-6),
+    "stencil_8x32": (1e-6, 1e-6), "st16x16": (1e-6, 1e-6), "st16x16_ragged": (1e-6, 1e-6), "st32x32": (1e-6, 1e-6),
+    "fd_8x8_3d": (1e-6, 1e-6), "fd_4x4_2d": (1e-6, 1e-6),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_hash_mode_takes_the_oracles_trajectory_z(oracle, name):
+    pr = CASES[name]()
+    tol = {"dense_random": 1e-10}.get(name, pr.tolerance)
+    st, X, info = T.solve_problem(pr, "z", threshold=tol, max_iterations=300)
+    st0, X0, info0 = oracle.solve(pr, "z", threshold=tol, max_iterations=300, v3=T.hash_shadow_vector(pr).reshape(-1))
+    assert st == st0 == 0
+    assert info["iterations"] == info0["iterations"], "same shadow vector, same decisions (tfqmrgpu_core.hxx:239-298)"
+    assert info["flops"] == info0["flops"]
+    h, h0 = info["bound_history"], info0["bound_history"]
+    htol, rtol = Z_TOL[name]
+    assert len(h) == len(h0) and np.allclose(h, h0, rtol=htol, atol=0), np.abs(h / h0 - 1).max()
+    assert info["residual"] == pytest.approx(info0["residual"], rel=rtol)
+    assert np.abs(X - X0).max() <= 1e-7 * np.abs(X0).max()
+
+
+@pytest.mark.parametrize("name", ["fd_16x16_2d", "fd_16x16_small", "st16x16", "st16x16_ragged", "st32x32", "stencil_8x8"])
+def test_hash_mode_against_the_oracle_c(oracle, name):
+    # complex<float>: both sides round every product to 24 bits in a different order, the trajectories separate after a
+    # few iterations: the first two bounds agree to 1e-3, the count to within one iteration, both converge
+    pr = CASES[name]()
+    tol = 1e-4
+    st, X, info = T.solve_problem(pr, "c", threshold=tol, max_iterations=300)
+    st0, X0, info0 = oracle.solve(pr, "c", threshold=tol, max_iterations=300, v3=T.hash_shadow_vector(pr).reshape(-1))
+    assert st == st0 == 0
+    assert abs(info["iterations"] - info0["iterations"]) <= 1, (info["iterations"], info0["iterations"])
+    assert np.allclose(info["bound_history"][:2], info0["bound_history"][:2], rtol=1e-3, atol=0)
+    assert info["residual"] <= tol and np.abs(X - X0).max() <= 1e-3 * np.abs(X0).max()
+
+
+def _worker(tmp_path, tag, name, prec, tol, **env):
+    out = str(tmp_path / (tag + ".npz"))
+    e = dict(os.environ, **{k: str(v) for k, v in env.items()})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_env_worker.py"), out, name, prec, repr(tol)],
+                       env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return np.load(out)
+
+
+@pytest.mark.parametrize("name,prec,tol", [("fd_16x16_2d", "z", 1e-9), ("fd_16x16_2d", "c", 1e-4),
+                                           ("stencil:12:12:16:16:4:7:5", "z", 1e-9)])
+def test_recomputing_the_shadow_vector_changes_no_bit(tmp_path, name, prec, tol):
+    # TFQMRGPU_HASHV3=0 makes the 16 x 16 multiply kernels READ v3 (HASH = false, the variant the glibc-mode tests cover)
+    a = _worker(tmp_path, "recompute", name, prec, tol, TFQMRGPU_HASHV3=1)
+    b = _worker(tmp_path, "read", name, prec, tol, TFQMRGPU_HASHV3=0)
+    assert int(a["status"]) == int(b["status"]) == 0 and int(a["iterations"]) == int(b["iterations"])
+    assert np.array_equal(a["history"], b["history"]) and float(a["residual"]) == float(b["residual"])
+    assert np.array_equal(a["X"], b["X"])
+
+
+SWITCHES = [dict(TFQMRGPU_3M=0), dict(TFQMRGPU_3M=2), dict(TFQMRGPU_EPI_PREFETCH=0), dict(TFQMRGPU_ORDER=0),
+            dict(TFQMRGPU_DEPTH=1), dict(TFQMRGPU_DEPTH=4), dict(TFQMRGPU_CHUNK_KIB=64), dict(TFQMRGPU_ORDER_G=8)]
+
+
+@pytest.mark.parametrize("name,prec,tol", [("stencil:16:16:16:16:4:7:5", "z", 1e-9), ("stencil:8:8:32:32:2:3:13", "z", 1e-9),
+                                           ("stencil:12:12:8:8:4:5:5", "z", 1e-9)])
+def test_tuning_switches_change_code_paths_not_results(tmp_path, name, prec, tol):
+    """every non-default value of the environment switches: same status and iteration count, the
+    solution within rounding (a switch may change the order of a sum: chunk length, three-product form)"""
+    base = _worker(tmp_path, "default", name, prec, tol)
+    assert int(base["status"]) == 0
+    for n, sw in enumerate(SWITCHES):
+        got = _worker(tmp_path, "sw%d" % n, name, prec, tol, **sw)
+        assert int(got["status"]) == 0 and int(got["iterations"]) == int(base["iterations"]), sw
+        assert np.allclose(got["history"], base["history"], rtol=1e-6, atol=0), sw
+        assert np.abs(got["X"] - base["X"]).max() <= 1e-9 * np.abs(base["X"]).max(), sw
+        if "TFQMRGPU_DEPTH" in sw or "TFQMRGPU_ORDER" in sw or "TFQMRGPU_ORDER_G" in sw or "TFQMRGPU_EPI_PREFETCH" in sw:
+            assert np.array_equal(got["X"], base["X"]), sw   # these change WHEN things run, never what is added to what

@@ -4,7 +4,6 @@ must take the iterations of the single-rank run and return bit-identical solutio
 columns are independent systems, the default shadow vector is a hash of (column, row, element), every reduction is
 in a fixed order.  At most 4 processes touch the GPU.  Run with `pytest -m gpu`."""
 import os
-import socket
 import subprocess
 import sys
 
@@ -12,15 +11,9 @@ import numpy as np
 import pytest
 
 import tfqmrgpu_amd as T
-from conftest import ROOT, load_problem
+from conftest import ROOT, load_problem, torchrun
 
 pytestmark = pytest.mark.gpu
-
-
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
 
 
 @pytest.mark.parametrize("world,name,prec,tol", [(2, "fd_16x16_small", "z", 1e-9), (3, "stencil_8x8", "z", 1e-9),
@@ -28,14 +21,9 @@ def _free_port():
 def test_ranks_sharing_one_gpu(tmp_path, world, name, prec, tol):
     out = str(tmp_path / "sharded.npz")
     env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+    cmd = torchrun(world) + [
            os.path.join(ROOT, "tests", "_gpu_rank_worker.py"), out, name, prec, repr(tol)]
-    for attempt in range(3):   # the free port can be taken again before torchrun listens on it: a rendezvous error, nothing has run yet
-        cmd[cmd.index("--master-port") + 1] = str(_free_port())
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-        if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
-            break
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     g = np.load(out)
     pr = load_problem(name)

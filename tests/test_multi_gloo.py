@@ -4,34 +4,22 @@ exactly the iterations of the single-rank run and return bit-identical solution 
 columns are independent systems and all ranks take the same continue/probe/stop decisions
 (SURVEY.md section 8e)."""
 import os
-import socket
 import subprocess
 import sys
 
 import numpy as np
 import pytest
 
-from conftest import ROOT, load_problem
-
-
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+from conftest import ROOT, load_problem, torchrun
 
 
 @pytest.mark.parametrize("world,name,tol", [(2, "fd_16x16_small", 1e-9), (3, "stencil_8x8", 1e-9), (2, "fd_4x4_2d", 1e-9)])
 def test_sharded_solve_equals_single_rank(oracle, tmp_path, world, name, tol):
     out = str(tmp_path / "sharded.npz")
     env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+    cmd = torchrun(world) + [
            os.path.join(ROOT, "tests", "_gloo_worker.py"), out, name, repr(tol)]
-    for attempt in range(3):   # the free port can be taken again before torchrun listens on it: a rendezvous error, nothing has run yet
-        cmd[cmd.index("--master-port") + 1] = str(_free_port())
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-        if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
-            break
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     g = np.load(out)
     pr = load_problem(name)

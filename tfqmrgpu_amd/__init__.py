@@ -33,7 +33,7 @@ EXT_SYMBOLS = [  # include/tfqmrgpu_ext.h
     "tfqmrgpuExt_planView", "tfqmrgpuExt_getBoundHistory", "tfqmrgpuExt_setProfiling", "tfqmrgpuExt_getProfile",
     "tfqmrgpuExt_getProfileGated",
     "tfqmrgpuExt_setShadowMode",
-    "tfqmrgpuExt_setShadowVector", "tfqmrgpuExt_multiply", "tfqmrgpuExt_shardColumns",
+    "tfqmrgpuExt_setShadowVector", "tfqmrgpuExt_getShadowVector", "tfqmrgpuExt_multiply", "tfqmrgpuExt_shardColumns",
     "tfqmrgpuExt_freeShard", "tfqmrgpuExt_commUniqueId", "tfqmrgpuExt_commInit",
     "tfqmrgpuExt_commDestroy", "tfqmrgpuExt_setReduceCallback", "tfqmrgpuExt_setOperator",
 ]
@@ -114,6 +114,7 @@ def load_library(path=LIB_PATH):
     lib.tfqmrgpuExt_getProfileGated.argtypes = [P, P, P]
     lib.tfqmrgpuExt_setShadowMode.argtypes = [P, I]
     lib.tfqmrgpuExt_setShadowVector.argtypes = [P, P, P]
+    lib.tfqmrgpuExt_getShadowVector.argtypes = [P, P, P]
     lib.tfqmrgpuExt_multiply.argtypes = [P, C.c_char, I, I, C.c_uint32, P, P, P, P, P]
     lib.tfqmrgpuExt_shardColumns.argtypes = [I, P, I, P, P, I, P, I, I, I, C.POINTER(Shard)]
     lib.tfqmrgpuExt_freeShard.argtypes = [C.POINTER(Shard)]
@@ -231,6 +232,12 @@ class Solver:
             self.buffer = C.c_void_p(device_ptr)
         _check(lib.tfqmrgpu_bsrsv_setBuffer(self.handle, self.plan, self.buffer), "tfqmrgpu_bsrsv_setBuffer")
 
+    def get_shadow_vector(self):
+        """the shadow vector v3 in use: float [nnzbX, 2, LM, LN], caller's block order"""
+        v3 = np.zeros((self.problem.nnzbX, 2, self.LM, self.LN), dtype=np.float32)
+        _check(lib.tfqmrgpuExt_getShadowVector(self.handle, self.plan, _ptr(v3)), "tfqmrgpuExt_getShadowVector")
+        return v3
+
     # -- values ----------------------------------------------------------------------------------------
     def _real_dtype(self):
         return np.float64 if self.precision == "z" else np.float32
@@ -324,6 +331,20 @@ class Solver:
 
     def __exit__(self, *a):
         self.close()
+
+
+def hash_shadow_vector(pr):
+    """numpy restatement of the library's default shadow vector (tfq_device.hpp: shadow_key / shadow_value), float
+    [nnzbX, 2, LM, LN] in the caller's block order -- what tests feed to the CPU oracle"""
+    from .problems import _splitmix64
+    rows = np.repeat(np.arange(pr.mb, dtype=np.uint64), np.diff(pr.rowPtrX))
+    cols = (pr.colIndX.astype(np.int64) - pr.index_offset).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        key = _splitmix64((cols << np.uint64(32)) | rows) ^ np.uint64(1234)
+        e = np.arange(2 * pr.LM * pr.LN, dtype=np.uint64) * np.uint64(0xD1342543DE82EF95)
+        h = _splitmix64(key[:, None] + e[None, :])
+    v = ((h >> np.uint64(40)) + np.uint64(1)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return v.reshape(pr.nnzbX, 2, pr.LM, pr.LN)
 
 
 def solve_problem(pr, precision="z", threshold=None, max_iterations=2000, transA="n", shadow_mode=SHADOW_HASH, stream=None):

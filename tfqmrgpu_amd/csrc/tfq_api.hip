@@ -754,6 +754,14 @@ tfqmrgpuStatus_t tfqmrgpuExt_setShadowVector(tfqmrgpuHandle_t handle, tfqmrgpuBs
                            TFQMRGPU_LAYOUT_RRRRIIII, false, false);
 }
 
+tfqmrgpuStatus_t tfqmrgpuExt_getShadowVector(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, float* v3) {
+    auto p = asPlan(plan); auto h = (Handle*)handle;
+    if (!p || !h || !v3 || !p->buffer) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    DevPlan const d = resolve(*p);
+    return transfer_blocks(*p, (hipStream_t)h->stream, 1, false, d.v3, (void*)v3, d.u2i, p->nnzbX, p->LM, p->LN,
+                           TFQMRGPU_LAYOUT_RRRRIIII, false, false);
+}
+
 tfqmrgpuStatus_t tfqmrgpuExt_multiply(tfqmrgpuHandle_t handle, char precision, int lm, int ln,
     uint32_t nnzbY, uint32_t const* starts_d, uint32_t const* pairs_d, void const* A_d, void const* X_d, void* Y_d)
 {
