@@ -9,14 +9,20 @@ matrices are resident in HBM before the timed region.  `value` = reference flop 
 (tfqmrgpu_bsrsv_getInfo, the number the reference's own `bench_tfqmrgpu tfQMR` divides by its solver
 time, bench_tfqmrgpu.cu:200-204) / wall time, summed over all GPUs.
 
---gpus N (launched by torch.distributed.run, one process per GPU): weak scaling, every rank owns its own
-49 block columns of a N*49-column system (same A, same sparsity, own shadow vector); the only
+--gpus N, one process per GPU: weak scaling by default, every rank owns its own 49 block columns of a N*49-column
+system (same A, same sparsity, own shadow vector); `--workload cfg4` is BASELINE config 4, strong scaling: the 256
+block columns of one 16x16 complex<double> system split N ways with the product's tfqmrgpuExt_shardColumns.  The only
 communication is the RCCL max-all-reduce of the stopping-test scalars inside the solver.
+Launch: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N` (what the driver does), or
+plain `python bench.py --gpus N`: bench.py then starts that launcher itself as a CHILD process before anything in this
+process has touched the GPU, relays rank 0's JSON line and exits with the child's code (`--launcher` forces the same
+path for N = 1: process group + RCCL communicator with one rank).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,7 +35,7 @@ HBM_PEAK_GBS = 8000.0                          # /opt/skills/guides/MI355X_MICRO
 MFMA_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}  # dense matrix peaks (f64: SURVEY.md 8d public spec, f32: guide)
 
 
-def build_problem(name, rank):
+def build_problem(name, rank, world=1):
     from tfqmrgpu_amd import problems as PR
     from tfqmrgpu_amd.fd_generator import FDExample
     if name == "fd2d_16x16_z":
@@ -51,6 +57,13 @@ def build_problem(name, rank):
         if prec == "c":
             pr.tolerance = 1e-4
         desc = "5-point block stencil %sx%s, %sx%s complex<%s>, %s block columns" % (nx, ny, lm, ln, "double" if prec == "z" else "float", nc)
+    elif name == "cfg4":                # BASELINE configs[3]: 256 block columns (4096 RHS) of ONE system, sharded over the ranks
+        import tfqmrgpu_amd as T
+        full = PR.stencil_2d(128, 128, 16, 16, 256, seed=4)
+        pr, _, _ = T.shard_columns(full, world, rank)
+        desc = ("5-point block stencil 128x128, 16x16 complex<double>, 256 block columns (4096 RHS) split over %d GPU%s: "
+                "columns %d..%d here" % (world, "s" if world > 1 else "", pr.first_col, pr.first_col + pr.n_cols - 1))
+        return pr, "z", desc
     else:
         raise SystemExit("unknown workload " + name)
     ncols = int(pr.colIndX.max()) + 1
@@ -89,20 +102,51 @@ def roof(bytes_, flops, ms, prec):
 
 
 def cpu_baseline(pr, prec, threads):
-    """the CPU oracle (port of the reference CPU path) on a bounded sample: ONE tfQMR iteration + final probe
-    (3 block-sparse multiplies + all vector ops) of the same system"""
+    """The CPU path beside the GPU number, on a bounded sample of the same system: ONE tfQMR iteration + the final residual
+    probe (3 of the BSR multiplies, all vector operations), timed three ways:
+      * kind "reference": oracle/_ref, the reference's own CPU library (tfqmrgpu.cu compiled with HAS_NO_CUDA by
+        oracle/Makefile where /root/reference existed; it travels with the tree as a built file), ONE thread -- the reference
+        solver has no OpenMP (bench_tfqmrgpu.cu:358-365 is its only parallel loop);
+      * value_1t: the oracle (this repository's restatement, "port") with one thread;
+      * value_omp: the oracle with its multiply threaded over all cores of the CPU share.
+    `value` is the reference's figure when oracle/_ref is there, the 1-thread port otherwise."""
     from oracle import pyoracle as O
     O.lib()
-    used = O.set_threads(threads)
     an = O.analyse(pr)
-    t0 = time.time()
-    st, X, info = O.solve(pr, prec, threshold=pr.tolerance, max_iterations=1, plan=an)
-    dt = time.time() - t0
-    return dict(value=round(info["flops"] / dt / 1e12, 6), unit="TFLOP/s", cores=used, kind="port",
-                sample="1 tfQMR iteration + residual probe (3 of the BSR multiplies, all vector ops) of the same system: "
-                       "%.2f GFlop in %.2f s; multiply threaded with OpenMP, vector ops single-threaded like the reference"
-                       % (info["flops"] / 1e9, dt),
-                seconds=round(dt, 3))
+
+    def port(nthreads):
+        used = O.set_threads(nthreads)
+        t0 = time.time()
+        st, X, info = O.solve(pr, prec, threshold=pr.tolerance, max_iterations=1, plan=an)
+        dt = time.time() - t0
+        return info["flops"], dt, used
+    fl, dt_omp, used = port(threads)
+    _, dt_1, _ = port(1)
+    O.set_threads(threads)
+    out = dict(unit="TFLOP/s", value_1t=round(fl / dt_1 / 1e12, 6), seconds_1t=round(dt_1, 3),
+               value_omp=round(fl / dt_omp / 1e12, 6), seconds_omp=round(dt_omp, 3), cores_omp=used, nproc=os.cpu_count())
+    sample = ("1 tfQMR iteration + residual probe (3 of the BSR multiplies, all vector ops) of the same system, %.2f GFlop by the "
+              "reference's count" % (fl / 1e9))
+    if O.have_ref():
+        ref = O.Reference()
+        t0 = time.time()
+        st, X, info = ref.solve_staged(pr, prec, threshold=pr.tolerance, max_iterations=1)
+        dt = time.time() - t0
+        out.update(value=round(info["flops"] / dt / 1e12, 6), cores=1, kind="reference", seconds=round(dt, 3),
+                   sample=sample + "; the reference's own CPU library (HAS_NO_CUDA build), single-threaded as the reference is")
+    else:
+        out.update(value=out["value_1t"], cores=1, kind="port", seconds=out["seconds_1t"],
+                   sample=sample + "; the oracle (restatement of the reference CPU path), one thread; oracle/_ref not present")
+    return out
+
+
+def launch_ranks(n, argv):
+    """python bench.py --gpus N without a launcher: start N ranks as children of THIS process, which has not touched the GPU
+    (nothing imported torch yet), relay the output, exit with the launcher's code"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(n), os.path.abspath(__file__)] + [a for a in argv if a != "--launcher"]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -115,15 +159,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--multiply-reps", type=int, default=20)
     ap.add_argument("--no-hbm-multiply", action="store_true", help="skip the one-block-column (HBM-bound) multiply measurement")
+    ap.add_argument("--launcher", action="store_true", help="go through torch.distributed.run even for one rank")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and (args.gpus > 1 or args.launcher):
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("bench.py --gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"
     torch.cuda.set_device(local)
     # under torch.distributed.run (RANK set) the multi-rank path is taken even for one rank, so that it can be
@@ -135,7 +182,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import tfqmrgpu_amd as T
-    pr, prec, desc = build_problem(args.workload, rank)
+    pr, prec, desc = build_problem(args.workload, rank, world)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         s = T.Solver(stream.cuda_stream)
@@ -155,7 +202,7 @@ def main():
             uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
             ok = torch.tensor([1 if T.lib.tfqmrgpuExt_commInit(s.handle, world, rank, uid) == 0 else 0], dtype=torch.int32, device="cuda")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            reduce_path = "rccl (library's own communicator on the solver stream)"
+            reduce_path = "rccl (library's own communicator on the solver stream, %d rank%s)" % (world, "s" if world > 1 else "")
             if int(ok.item()) == 0:
                 # the library could not set up its own communicator on every rank: same protocol through the host
                 # callback, reduced with torch.distributed (slower: one host round trip per stopping test)
@@ -225,8 +272,9 @@ def main():
                       gated_off_launches=per_kernel[dom]["gated_off_launches"], avg_ms_all_launches=per_kernel[dom]["avg_ms_all_launches"],
                       algorithmic_bytes=int(model[dom][0]), algorithmic_flops=float(model[dom][1]), traffic=None)
             tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tp):
+            if os.path.exists(tp):   # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc cannot run inside this timing run)
                 rl["traffic"] = json.load(open(tp)).get(args.workload, {}).get(dom)
+                rl["traffic_source"] = "profiles/pmc_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE of scripts/pmc_collect.sh, kept from the latest PMC run; not measured in this run)"
 
             # the stand-alone multiply on the same pair list (what the reference times in `bench_tfqmrgpu multi`)
             real = torch.float64 if prec == "z" else torch.float32
@@ -301,7 +349,7 @@ def main():
                 "value": round(flops / elapsed / 1e12, 4), "unit": "TFLOP/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "higher_is_better": True, "scaling": "strong" if args.workload == "cfg4" else "weak", "vs_baseline": None,
                 "dtype": "f64" if prec == "z" else "f32", "data": "synthetic",
                 "config": {"workload": desc, "name": args.workload, "mb": pr.mb, "nnzbA": pr.nnzbA, "nnzbX_per_gpu": pr.nnzbX,
                            "block_columns_per_gpu": view["nCols"], "rhs_per_gpu": view["nCols"] * pr.LN, "pairs": nPairs,
