@@ -244,3 +244,27 @@ def test_create_plan_random_patterns_bit_exact(oracle):
                 for k in PLAN_KEYS + ("original_bsrColIndX",):
                     assert np.array_equal(r[k], an[k]), (case, k)
     assert nonempty > 60
+
+
+def test_block_column_limit_and_stray_indices():
+    """the compressed block column is 16 bit in the reference (colIndex_t, tfqmrgpu.hxx:59, asserted at
+    tfqmrgpu_core.hxx:81): 65 536 block columns are accepted, one more is refused with NO_IMPLEMENTATION instead of being
+    truncated; a stray column index (range 2^31) costs nothing -- the columns are compressed from the distinct values"""
+    import tfqmrgpu_amd as T
+    for ncols, want in ((65536, 0), (65537, 19)):
+        cols = np.arange(ncols, dtype=np.int32)
+        pr = T.Problem([0, 1], [0], np.eye(4)[None], [0, ncols], cols, [0, ncols], cols, np.zeros((ncols, 4, 4)), None, 1e-9)
+        with T.Solver() as s:
+            st = T.lib.tfqmrgpu_bsrsv_createPlan(s.handle, C.byref(s.plan), pr.mb, T._ptr(pr.rowPtrA), pr.nnzbA, T._ptr(pr.colIndA),
+                                                 T._ptr(pr.rowPtrX), pr.nnzbX, T._ptr(pr.colIndX), T._ptr(pr.rowPtrB), pr.nnzbB,
+                                                 T._ptr(pr.colIndB), 0, 0)
+            assert T.decode(st)[0] == want
+            if want == 0:
+                v = s.plan_view()
+                assert v["nCols"] == 65536 and v["colindx"][-1] == 65535
+    cols = np.array([5, 2147483600, -2147483600], dtype=np.int32)
+    pr = T.Problem([0, 1], [0], np.eye(4)[None], [0, 3], cols, [0, 3], cols, np.zeros((3, 4, 4)), None, 1e-9)
+    with T.Solver() as s:
+        s.create_plan(pr)
+        v = s.plan_view()
+        assert v["nCols"] == 3 and list(v["colindx"]) == [1, 2, 0] and list(v["original_bsrColIndX"]) == [-2147483600, 5, 2147483600]

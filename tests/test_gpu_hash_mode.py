@@ -109,7 +109,8 @@ def test_recomputing_the_shadow_vector_changes_no_bit(tmp_path, name, prec, tol)
 
 
 SWITCHES = [dict(TFQMRGPU_3M=0), dict(TFQMRGPU_3M=2), dict(TFQMRGPU_EPI_PREFETCH=0), dict(TFQMRGPU_ORDER=0),
-            dict(TFQMRGPU_DEPTH=1), dict(TFQMRGPU_DEPTH=4), dict(TFQMRGPU_CHUNK_KIB=64), dict(TFQMRGPU_ORDER_G=8)]
+            dict(TFQMRGPU_DEPTH=1), dict(TFQMRGPU_DEPTH=4), dict(TFQMRGPU_CHUNK_KIB=64), dict(TFQMRGPU_ORDER_G=8),
+            dict(TFQMRGPU_ILV=0)]     # ILV=0: 16 x 16 z plans keep the native element order (k_spmm_mfma instead of k_spmm_ilv16)
 
 
 @pytest.mark.parametrize("name,prec,tol", [("stencil:16:16:16:16:4:7:5", "z", 1e-9), ("stencil:8:8:32:32:2:3:13", "z", 1e-9),

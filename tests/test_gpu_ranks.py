@@ -42,3 +42,19 @@ def test_ranks_sharing_one_gpu(tmp_path, world, name, prec, tol):
     assert max(g["residual"]) == info["residual"]
     assert np.array_equal(g["X"], X)                                  # bit-identical solution blocks
     assert min(g["calls"]) >= info["iterations"]
+
+
+def test_a_failing_rank_stops_every_rank(tmp_path):
+    """a rank whose operator fails completes its slot with the failure marked in the reduced record: every rank stops at that
+    slot and returns an error, none waits in an all-reduce for ever (the reduction carries {bound, alive, a rank failed})"""
+    out = str(tmp_path / "status.txt")
+    env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = torchrun(2) + [os.path.join(ROOT, "tests", "_gpu_fail_worker.py"), out, "1", "5"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)    # a hang would end here
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rows = [tuple(int(v) for v in line.split()) for line in open(out)]
+    assert len(rows) == 2
+    (r0, st0, calls0), (r1, st1, calls1) = sorted(rows)
+    assert T.decode(st1)[0] == 14                       # the failing rank returns its operator's status
+    assert st0 != 0 and T.decode(st0)[0] == 2           # the other one: stopped by a peer (LAUNCH_FAILED class)
+    assert calls1 in (5, 6) and calls0 in (5, 6)        # both stopped in the slot of the failure (2 operator calls per iteration), far from the 300 iterations asked for

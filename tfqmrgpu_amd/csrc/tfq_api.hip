@@ -28,6 +28,7 @@ DevPlan resolve(Plan const& p) {
     d.nChunks = uint32_t(p.chunks.col.size());
     static int const hashEnv = [] { auto v = std::getenv("TFQMRGPU_HASHV3"); return v ? std::atoi(v) : 1; }();
     d.hashV3 = (p.v3IsHash && hashEnv) ? 1 : 0;   // TFQMRGPU_HASHV3=0: the multiply kernels read v3 also in hash mode
+    d.ilv = p.ilv;
     d.x = at(p.wX); d.v4 = at(p.wV4); d.v5 = at(p.wV5); d.v6 = at(p.wV6); d.v7 = at(p.wV7);
     d.v8 = at(p.wV8); d.v9 = at(p.wV9); d.B = at(p.wB); d.A = at(p.wA); d.v3 = (float*)at(p.wV3);
     d.rho = at(p.wRho); d.alfa = at(p.wAlfa); d.beta = at(p.wBeta); d.c67 = at(p.wC67); d.eta = at(p.wEta);
@@ -91,9 +92,9 @@ static tfqmrgpuStatus_t transfer_blocks(Plan& p, hipStream_t s, int direction, b
         char* h = (char*)host + size_t(first) * blockBytes;
         if (0 == direction) {
             TFQ_HIP(hipMemcpyAsync(st.ptr, h, n * blockBytes, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
-            launch_convert(0, dbl, native, st.ptr, u2n, first, n, nR, nC, layout, trans, conj, s);
+            launch_convert(0, dbl, native, st.ptr, u2n, first, n, nR, nC, layout, trans, conj, p.ilv, s);
         } else {
-            launch_convert(1, dbl, native, st.ptr, u2n, first, n, nR, nC, layout, trans, conj, s);
+            launch_convert(1, dbl, native, st.ptr, u2n, first, n, nR, nC, layout, trans, conj, p.ilv, s);
             TFQ_HIP(hipMemcpyAsync(h, st.ptr, n * blockBytes, hipMemcpyDeviceToHost, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
         }
         // the stage is reused by the next batch and the host array belongs to the caller
@@ -130,23 +131,34 @@ bool Rccl::load() {
 }
 enum { kNcclDouble = 8, kNcclMax = 2 };
 
-// max-reduce ctl->red[off..off+1] over all ranks
-static tfqmrgpuStatus_t reduce_over_ranks(Handle& h, DevPlan const& d, int off, hipStream_t s) {
-    double* red = &d.ctl->red[off];
+// max-reduce n doubles of device memory over all ranks (in place, on the solver's stream)
+static tfqmrgpuStatus_t reduce_over_ranks(Handle& h, double* red, int n, hipStream_t s) {
     if (h.comm) {
-        int const rc = g_rccl.AllReduce(red, red, 2, kNcclDouble, kNcclMax, h.comm, s);
+        int const rc = g_rccl.AllReduce(red, red, size_t(n), kNcclDouble, kNcclMax, h.comm, s);
         return rc ? TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED) : TFQMRGPU_STATUS_SUCCESS;
     }
     if (h.reduceFn) {
-        double v[2];
-        TFQ_HIP(hipMemcpyAsync(v, red, sizeof v, hipMemcpyDeviceToHost, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        double v[4];
+        TFQ_HIP(hipMemcpyAsync(v, red, n * sizeof(double), hipMemcpyDeviceToHost, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
         TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)
-        h.reduceFn(h.reduceCtx, v, 2);
-        TFQ_HIP(hipMemcpyAsync(red, v, sizeof v, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        h.reduceFn(h.reduceCtx, v, n);
+        TFQ_HIP(hipMemcpyAsync(red, v, n * sizeof(double), hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
         TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)
     }
     return TFQMRGPU_STATUS_SUCCESS;
 }
+
+// HIP events that are destroyed on every path out of a solve
+struct EventList {
+    std::vector<hipEvent_t> v;
+    bool create(size_t n) {
+        v.reserve(n);
+        for (size_t i = 0; i < n; ++i) { hipEvent_t e; if (hipSuccess != hipEventCreate(&e)) return false; v.push_back(e); }
+        return true;
+    }
+    ~EventList() { for (auto e : v) (void)hipEventDestroy(e); }
+    hipEvent_t operator[](size_t i) const { return v[i]; }
+};
 
 // ---- the tfQMR driver -----------------------------------------------------------------------------
 // Optional roctx ranges around the two phases of a solve, named like the reference's NVTX ranges (tfqmrgpu_core.hxx:29,
@@ -185,45 +197,62 @@ static Roctx const& roctx() { static Roctx const r; return r; }
 // enqueues iteration it+DEPTH.  Iterations enqueued after the solve has stopped cost a few empty
 // launches.  Every rank enqueues the same number of iterations, so collectives always match.
 static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
-    if (!p.buffer) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
-    if ('z' != p.precision && 'c' != p.precision) return err(TFQMRGPU_PRECISION_MISSMATCH, __LINE__ % 10000, p.precision);
     hipStream_t const s = (hipStream_t)h.stream;
-    DevPlan const d = resolve(p);
     bool const multi = (h.comm != nullptr) || (h.reduceFn != nullptr);
-
     constexpr int DEPTH = Plan::kDepth;
     constexpr int NK = TFQMRGPU_PROFILE_CLASSES;
-    // pinned ring + events live with the plan (hipHostMalloc / event creation cost more than a small solve)
-    if (!p.ring) {
-        TFQ_HIP(hipHostMalloc((void**)&p.ring, DEPTH * sizeof(Ctl), hipHostMallocDefault), TFQMRGPU_STATUS_ALLOCATION_FAILED)
-        for (auto& e : p.ringEvent) { hipEvent_t ev_; (void)hipEventCreateWithFlags(&ev_, hipEventDisableTiming); e = (void*)ev_; }
-    }
-    Ctl* const ring = (Ctl*)p.ring;
-    hipEvent_t ev[DEPTH];
-    for (int i = 0; i < DEPTH; ++i) ev[i] = (hipEvent_t)p.ringEvent[i];
-    // profiling: NK+1 timing events per in-flight iteration, event k sits in front of kernel class k
-    bool const prof = p.profiling;
-    std::vector<hipEvent_t> pev(prof ? DEPTH * (NK + 1) : 0);
-    for (auto& e : pev) (void)hipEventCreate(&e);
-    for (int k = 0; k < NK; ++k) { p.profLaunches[k] = 0; p.profMs[k] = 0; p.profGatedLaunches[k] = 0; p.profGatedMs[k] = 0; }
-
-    p.boundHistory.clear();
-    p.iterations_needed = maxIt; p.flops_performed = 0;
     // How far the host runs ahead: 2 slots.  Every slot that is still queued when the solve stops costs ~14 empty
     // launches, and enqueuing a slot (~50 us) is never slower than executing one (>= 60 us even for tiny systems), so a
     // deeper queue only adds to the tail (measured: 4 -> 2 gains 8 % on the 2-iteration solves of config 3, 5 % on
     // 1000-block systems, 0.8 % on P2; 1 loses on small systems).  TFQMRGPU_DEPTH = 1..4 overrides.
     static int const depthEnv = [] { auto v = std::getenv("TFQMRGPU_DEPTH"); return v ? std::atoi(v) : 0; }();
     int ahead = (depthEnv >= 1 && depthEnv <= DEPTH) ? depthEnv : 2;
-    if (multi) {   // every rank must enqueue the same number of slots (the collectives have to match): the deepest wish wins
-        double vote[2] = { double(ahead), 0. };
-        TFQ_HIP(hipMemcpyAsync(&d.ctl->red[0], vote, sizeof vote, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
-        if (auto const st = reduce_over_ranks(h, d, 0, s)) return st;
-        TFQ_HIP(hipMemcpyAsync(vote, &d.ctl->red[0], sizeof vote, hipMemcpyDeviceToHost, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+
+    // what this rank can tell before it touches the device
+    tfqmrgpuStatus_t early = TFQMRGPU_STATUS_SUCCESS;
+    if (!p.buffer) early = TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    else if ('z' != p.precision && 'c' != p.precision) early = err(TFQMRGPU_PRECISION_MISSMATCH, __LINE__ % 10000, p.precision);
+    if (multi) {
+        // One collective in front of every solve: {deepest queue any rank wants, some rank cannot start}.  Every rank must
+        // enqueue the same number of slots (the collectives have to match), and a rank that returned here on its own would
+        // leave its peers waiting in their first all-reduce for ever -- so the refusal travels through the same reduction.
+        if (!h.voteBuf) TFQ_HIP(hipMalloc((void**)&h.voteBuf, 4 * sizeof(double)), TFQMRGPU_STATUS_ALLOCATION_FAILED)
+        double vote[2] = { double(ahead), early ? 1. : 0. };
+        TFQ_HIP(hipMemcpyAsync(h.voteBuf, vote, sizeof vote, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        if (auto const st = reduce_over_ranks(h, h.voteBuf, 2, s)) return st;
+        TFQ_HIP(hipMemcpyAsync(vote, h.voteBuf, sizeof vote, hipMemcpyDeviceToHost, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
         TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)
         ahead = std::min(DEPTH, std::max(1, int(vote[0])));
+        if (!early && vote[1] > 0.) early = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);   // a peer cannot start: nobody does
     }
-    { RoctxRange const range(roctx(), "tfQMR preparation"); vec_launch(VEC_SETUP, d, tol, maxIt, s); }
+    if (early) return early;
+    DevPlan const d = resolve(p);
+
+    // pinned ring + events live with the plan (hipHostMalloc / event creation cost more than a small solve)
+    if (!p.ring) {
+        TFQ_HIP(hipHostMalloc((void**)&p.ring, DEPTH * sizeof(Ctl), hipHostMallocDefault), TFQMRGPU_STATUS_ALLOCATION_FAILED)
+        for (auto& e : p.ringEvent) {
+            hipEvent_t ev_ = nullptr;
+            if (hipSuccess != hipEventCreateWithFlags(&ev_, hipEventDisableTiming)) {
+                for (auto& f : p.ringEvent) { if (f) (void)hipEventDestroy((hipEvent_t)f); f = nullptr; }
+                (void)hipHostFree(p.ring); p.ring = nullptr;
+                return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED);
+            }
+            e = (void*)ev_;
+        }
+    }
+    Ctl* const ring = (Ctl*)p.ring;
+    hipEvent_t ev[DEPTH];
+    for (int i = 0; i < DEPTH; ++i) ev[i] = (hipEvent_t)p.ringEvent[i];
+    // profiling: NK+1 timing events per in-flight iteration, event k sits in front of kernel class k
+    bool const prof = p.profiling;
+    EventList pev;
+    if (prof && !pev.create(size_t(DEPTH) * (NK + 1))) return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED);
+    for (int k = 0; k < NK; ++k) { p.profLaunches[k] = 0; p.profMs[k] = 0; p.profGatedLaunches[k] = 0; p.profGatedMs[k] = 0; }
+
+    p.boundHistory.clear();
+    p.iterations_needed = maxIt; p.flops_performed = 0;
+    { RoctxRange const range(roctx(), "tfQMR preparation"); TFQ_HIP(vec_launch(VEC_SETUP, d, tol, maxIt, s), TFQMRGPU_STATUS_LAUNCH_FAILED) }
     RoctxRange const range(roctx(), "tfQMR iterations");
 
     tfqmrgpuStatus_t fail = TFQMRGPU_STATUS_SUCCESS;
@@ -250,42 +279,49 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         auto const i2u = (uint32_t const*)(yu + up256(vecBytes));
         auto const colU = (uint16_t const*)((char const*)i2u + up256(size_t(p.nnzbX) * 4));
         launch_convert(1, d.dbl, (EPI_RESIDUAL == epi) ? d.x : d.v6, xu, d.u2i, 0, p.nnzbX, p.LM, p.LN,
-                       TFQMRGPU_LAYOUT_RRRRIIII, false, false, s);
+                       TFQMRGPU_LAYOUT_RRRRIIII, false, false, p.ilv, s);
         double fl = 0;
         auto const st = userOp(p.opCtx, yu, xu, colU, p.nnzbX, p.nCols, p.LM, p.LN, p.precision, (tfqmrgpuStream_t)s, &fl);
-        if (st && !fail) fail = st;
+        if (st && !fail) fail = st;   // the slot is completed all the same: its reduction tells the other ranks
         userFlops += fl;
         epilogue_launch(epi, d, yu, i2u, s);
     };
 
     // part 0: all kernels of one iteration slot (most of them gate themselves off); 1: without the probe; 2: probe only
+    static double const kOne = 1.;
+    // the max-reduction of a slot; a rank that has failed marks the record, so that every rank stops at this slot
+    auto reduce = [&](int what) {
+        if (fail && hipSuccess != hipMemcpyAsync(&d.ctl->red[3 * what + 2], &kOne, sizeof kOne, hipMemcpyHostToDevice, s)) return;
+        auto const st = reduce_over_ranks(h, &d.ctl->red[3 * what], 3, s);
+        if (st && !fail) fail = st;
+    };
     auto launches = [&](int slot, int part) {
-        auto mark = [&](int k) { if (prof) (void)hipEventRecord(pev[slot * (NK + 1) + k], s); };
+        auto mark = [&](int k) { if (prof && hipSuccess != hipEventRecord(pev[slot * (NK + 1) + k], s) && !fail) fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED); };
         if (part != 2) {
-            mark(TFQMRGPU_PROF_DEC35);            vec_launch(VEC_DEC35, d, 0, 0, s);
-            mark(TFQMRGPU_PROF_XPAY_V6);          vec_launch(VEC_XPAY_V6, d, 0, 0, s);
+            mark(TFQMRGPU_PROF_DEC35);            (void)vec_launch(VEC_DEC35, d, 0, 0, s);
+            mark(TFQMRGPU_PROF_XPAY_V6);          (void)vec_launch(VEC_XPAY_V6, d, 0, 0, s);
             mark(TFQMRGPU_PROF_SPMM_V4_DOT);      multiply(EPI_XPAY_DOT);
-            mark(TFQMRGPU_PROF_DEC34);            vec_launch(VEC_DEC34, d, 0, 0, s);
-            mark(TFQMRGPU_PROF_V5_NRM);           vec_launch(VEC_V5_NRM, d, 0, 0, s);
-            mark(TFQMRGPU_PROF_DECT_C67);         vec_launch(VEC_DECT_C67, d, 0, 0, s);
-            mark(TFQMRGPU_PROF_X_V6_V7);          vec_launch(VEC_X_V6_V7, d, 0, 0, s);
+            mark(TFQMRGPU_PROF_DEC34);            (void)vec_launch(VEC_DEC34, d, 0, 0, s);
+            mark(TFQMRGPU_PROF_V5_NRM);           (void)vec_launch(VEC_V5_NRM, d, 0, 0, s);
+            mark(TFQMRGPU_PROF_DECT_C67);         (void)vec_launch(VEC_DECT_C67, d, 0, 0, s);
+            mark(TFQMRGPU_PROF_X_V6_V7);          (void)vec_launch(VEC_X_V6_V7, d, 0, 0, s);
             mark(TFQMRGPU_PROF_SPMM_V5_NRM_DOT);  multiply(EPI_AXPY_NRM_DOT);
-            mark(TFQMRGPU_PROF_DECT_FINAL);       vec_launch(VEC_DECT_FIN, d, 0, 0, s);
+            mark(TFQMRGPU_PROF_DECT_FINAL);       (void)vec_launch(VEC_DECT_FIN, d, 0, 0, s);
             mark(TFQMRGPU_PROF_DECIDE);
             if (multi) {
                 launch_decide(d, 1, s);
-                auto const st = reduce_over_ranks(h, d, 0, s); if (st) fail = st;
+                reduce(0);
                 launch_decide(d, 2, s);
             } else launch_decide(d, 0, s);
             mark(TFQMRGPU_PROF_PROBE);
         }
         if (part != 1) {
-            vec_launch(VEC_X_FLUSH, d, 0, 0, s);
+            (void)vec_launch(VEC_X_FLUSH, d, 0, 0, s);
             multiply(EPI_RESIDUAL);
-            vec_launch(VEC_PROBE_COL, d, 0, 0, s);
+            (void)vec_launch(VEC_PROBE_COL, d, 0, 0, s);
             if (multi) {
                 launch_probe_decide(d, 1, s);
-                auto const st = reduce_over_ranks(h, d, 2, s); if (st) fail = st;
+                reduce(1);
                 launch_probe_decide(d, 2, s);
             } else launch_probe_decide(d, 0, s);
         }
@@ -293,8 +329,9 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
     };
     auto enqueue = [&](int slot, int part = 0) {
         launches(slot, part);
-        (void)hipMemcpyAsync(&ring[slot], d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s);
-        (void)hipEventRecord(ev[slot], s);
+        // a copy that did not start would be read as a stale "still running": both calls are checked
+        if ((hipSuccess != hipMemcpyAsync(&ring[slot], d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s) ||
+             hipSuccess != hipEventRecord(ev[slot], s)) && !fail) fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
     };
 
     Ctl last{};
@@ -304,7 +341,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         // the callback's kernels cannot look at the control block, so nothing is enqueued ahead of a decision:
         // one host round trip per iteration (and one per probe), like the reference (tfqmrgpu_core.hxx:235-304)
         for (int it = 0; it < maxIt && !fail && 0 == last.state; ++it) {
-            for (int part = 1; part <= 2 && !fail; ++part) {
+            for (int part = 1; part <= 2 && !fail; ++part) {   // (a failing operator still completes its slot: see reduce())
                 if (2 == part && !(0 == last.state && last.probe)) break;
                 enqueue(0, part);
                 if (hipSuccess != hipEventSynchronize(ev[0])) { fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED); break; }
@@ -348,8 +385,8 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         }
     }
     if (hipSuccess != hipGetLastError() && !fail) fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
-    for (auto& e : pev) (void)hipEventDestroy(e);
     if (fail) return fail;
+    if (4 == last.state) return TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);   // another rank reported a failure; all ranks stopped at the same slot
 
     // flop model of the reference: tfqmrgpu_linalg.hxx:587,625,684,703 and tfqmrgpu_blocksparse.hxx:198
     double const blk = double(p.LM) * p.LN, nX = p.nnzbX;
@@ -410,6 +447,7 @@ tfqmrgpuStatus_t tfqmrgpuDestroyHandle(tfqmrgpuHandle_t handle) {       // refer
     if (nullptr == handle) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
     auto h = (Handle*)handle;
     if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+    if (h->voteBuf) (void)hipFree(h->voteBuf);
     delete h;
     return TFQMRGPU_STATUS_SUCCESS;
 }
@@ -448,8 +486,11 @@ tfqmrgpuStatus_t tfqmrgpu_bsrsv_createPlan(tfqmrgpuHandle_t handle, tfqmrgpuBsrs
     auto p = new (std::nothrow) Plan();
     if (!p) return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED);
     p->indexOffset = indexOffset;
-    auto const st = analyse(*p, mb, bsrRowPtrA, nnzbA, bsrColIndA, bsrRowPtrX, nnzbX, bsrColIndX,
-                            bsrRowPtrB, nnzbB, bsrColIndB, indexOffset, echo);
+    tfqmrgpuStatus_t st;
+    try {   // no exception may cross the C boundary: a C or Fortran caller would be terminated instead of getting a status
+        st = analyse(*p, mb, bsrRowPtrA, nnzbA, bsrColIndA, bsrRowPtrX, nnzbX, bsrColIndX,
+                     bsrRowPtrB, nnzbB, bsrColIndB, indexOffset, echo);
+    } catch (std::bad_alloc const&) { st = TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED); }
     if (st) { delete p; return st; }   // (the reference leaks the plan on its error paths)
     *plan = (tfqmrgpuBsrsvPlan_t)p;
     return TFQMRGPU_STATUS_SUCCESS;
@@ -485,7 +526,9 @@ tfqmrgpuStatus_t tfqmrgpu_bsrsv_bufferSize(tfqmrgpuHandle_t handle, tfqmrgpuBsrs
     if (nullptr == pBufferSizeInBytes) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
     if (!blockSizeAllowed(LM, LN)) return err(TFQMRGPU_BLOCKSIZE_MISSING, LN, LM); // tfqmrgpu.cu:70
     // 'm' is accepted here and refused by solve, as in the reference (tfqmrgpu.cu:42-44); size it like 'c'
-    auto const st = layoutBuffer(*p, LM, LN, ('m' == prec) ? 'c' : prec);
+    tfqmrgpuStatus_t st;
+    try { st = layoutBuffer(*p, LM, LN, ('m' == prec) ? 'c' : prec); }
+    catch (std::bad_alloc const&) { return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED); }
     if (p->opScratch) { (void)hipFree(p->opScratch); p->opScratch = nullptr; }   // sized for the previous block shape
     p->precision = prec;
     p->buffer = nullptr;

@@ -17,17 +17,18 @@ struct Ctl {
     double target_bound2;      // probe when bound2 <= target_bound2
     double max_bound2;         // bound2 of the latest iteration: max_rhs(tau/|b|^2) * (2 it + 1)
     double residual2_reached;  // max_rhs |A x - b|^2/|b|^2 at the latest probe
-    double red[4];             // {max tau/|b|^2, any RHS alive, max res^2, any RHS unconverged}
+    double red[6];             // max-reduced over ranks: {max tau/|b|^2, any RHS alive, a rank failed} per iteration,
+                               //                          {max res^2, any RHS unconverged, a rank failed} per probe
     int32_t iteration;         // completed iterations
     int32_t maxIterations;
-    int32_t state;             // 0 running, 1 converged, 2 all RHS broke down, 3 out of iterations
+    int32_t state;             // 0 running, 1 converged, 2 all RHS broke down, 3 out of iterations, 4 stopped: a rank reported a failure
     int32_t probe;             // the true residual has to be computed now
     int32_t iterations_needed;
     int32_t nprobes;
     int32_t xpend;             // x += eta2*v7 of the last iteration has not been applied yet
     int32_t pad[1];
 };
-static_assert(sizeof(Ctl) == 96, "Ctl is copied as 96 bytes");
+static_assert(sizeof(Ctl) == 112, "Ctl is copied as a whole");
 
 // device pointers of one plan (all inside the user's work buffer)
 struct DevPlan {
@@ -35,6 +36,7 @@ struct DevPlan {
     bool dbl;
     uint32_t nCols, nnzbX, nnzbB, nnzbA, nChunks;
     int hashV3;                                // v3 holds the counter-based hash below: kernels may recompute instead of reading it
+    int ilv;                                   // element order inside a block plane: 0 native [r][s], 1 row pairs interleaved (see ilv_offset)
     void *x, *v4, *v5, *v6, *v7, *v8, *v9, *B, *A;
     float* v3;
     void *rho, *alfa, *beta, *c67, *eta;       // [nCols][2][LN] real
@@ -72,6 +74,16 @@ __host__ __device__ inline float shadow_value(uint64_t key, uint32_t e) {
 }
 #endif
 
+// ---- element order inside one plane (Re or Im) of a block -------------------------------------------------------------
+// native (the reference's, tfqmrgpu_linalg.hxx:332-345):   [r][s]            r = row (k for the transposed A blocks), s contiguous
+// row pairs interleaved (16 x 16 complex<double> plans):    [r/2][s][r%2]     two consecutive rows of one column are 16 contiguous bytes
+// The second form exists for the multiply: a lane of the 16x16x4 MFMA then fetches the operands of two k-steps, and the
+// two rows of a column that its accumulator registers hold, as ONE 16-byte access -- half the memory instructions for the
+// operands, the epilogue vectors and the stores (measured on P2: fused multiplies 0.684 -> 0.628 ms, profiles/r02_lab.txt).
+// Everything else (vector updates, reductions) is elementwise and only needs to know which column an element belongs to.
+__host__ __device__ inline int ilv_offset(int r, int s, int nC) { return ((r >> 1) * nC + s) * 2 + (r & 1); }
+__host__ __device__ inline int plane_offset(int ilv, int r, int s, int nC) { return ilv ? ilv_offset(r, s, nC) : r * nC + s; }
+
 enum { EPI_NONE = 0, EPI_XPAY_DOT = 1, EPI_AXPY_NRM_DOT = 2, EPI_RESIDUAL = 3 };
 
 // ---- launchers (tfq_kernels*.hip); all asynchronous on `s` ---------------------------------------
@@ -85,8 +97,9 @@ tfqmrgpuStatus_t launch_multiply(char precision, int lm, int ln, uint32_t nnzbY,
 // layout conversion between the caller's block layout and the native one (tfq_layout.hip)
 // direction 0: user -> native (setMatrix), 1: native -> user (getMatrix); one batch of user blocks
 // [firstUser, firstUser + nBlocks) whose raw bytes sit in `stage`; u2n: user -> native block index
+// ilv: element order of the library-side blocks (see ilv_offset)
 void launch_convert(int direction, bool dbl, void* native, void* stage, uint32_t const* u2n,
-    uint32_t firstUser, uint32_t nBlocks, int nR, int nC, int layout, bool trans, bool conj, hipStream_t s);
+    uint32_t firstUser, uint32_t nBlocks, int nR, int nC, int layout, bool trans, bool conj, int ilv, hipStream_t s);
 void launch_shadow_hash(DevPlan const& d, hipStream_t s);
 
 } // namespace tfq

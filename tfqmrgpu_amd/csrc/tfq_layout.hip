@@ -30,7 +30,7 @@ __device__ inline uint32_t user_offset(int layout, bool trans, int nR, int nC, i
 // (nullptr: identity, used for A and B; X-shaped operators pass the column-sorted permutation).
 template <typename R>
 __global__ __launch_bounds__(256) void k_convert(int direction, R* native, R* stage, uint32_t const* u2n,
-    uint32_t firstUser, int nR, int nC, int layout, bool trans, bool conj)
+    uint32_t firstUser, int nR, int nC, int layout, bool trans, bool conj, int ilv)
 {
     uint32_t const ub = firstUser + blockIdx.x;
     uint32_t const nb = u2n ? u2n[ub] : ub;
@@ -41,17 +41,18 @@ __global__ __launch_bounds__(256) void k_convert(int direction, R* native, R* st
         int const c = e / (nR * nC), r = (e % (nR * nC)) / nC, s = e % nC;
         uint32_t const uo = user_offset(layout, trans, nR, nC, r, s, c);
         R const sign = (conj && c) ? R(-1) : R(1);
-        if (0 == direction) nblock[e] = sign * ublock[uo];
-        else                ublock[uo] = sign * nblock[e];
+        int const ne = c * nR * nC + plane_offset(ilv, r, s, nC);   // where the library keeps element (c, r, s)
+        if (0 == direction) nblock[ne] = sign * ublock[uo];
+        else                ublock[uo] = sign * nblock[ne];
     }
 }
 
 void launch_convert(int direction, bool dbl, void* native, void* stage, uint32_t const* u2n,
-    uint32_t firstUser, uint32_t nBlocks, int nR, int nC, int layout, bool trans, bool conj, hipStream_t s)
+    uint32_t firstUser, uint32_t nBlocks, int nR, int nC, int layout, bool trans, bool conj, int ilv, hipStream_t s)
 {
     if (0 == nBlocks) return;
-    if (dbl) k_convert<double><<<dim3(nBlocks), dim3(256), 0, s>>>(direction, (double*)native, (double*)stage, u2n, firstUser, nR, nC, layout, trans, conj);
-    else     k_convert<float ><<<dim3(nBlocks), dim3(256), 0, s>>>(direction, (float*)native, (float*)stage, u2n, firstUser, nR, nC, layout, trans, conj);
+    if (dbl) k_convert<double><<<dim3(nBlocks), dim3(256), 0, s>>>(direction, (double*)native, (double*)stage, u2n, firstUser, nR, nC, layout, trans, conj, ilv);
+    else     k_convert<float ><<<dim3(nBlocks), dim3(256), 0, s>>>(direction, (float*)native, (float*)stage, u2n, firstUser, nR, nC, layout, trans, conj, ilv);
 }
 
 // ---- shadow vector: the counter-based hash of tfq_device.hpp written out (k_dot35 and the GLIBC/user modes read v3) ----
@@ -63,7 +64,11 @@ __global__ __launch_bounds__(256) void k_shadow_hash(DevPlan d) {
     for (uint32_t b = first; b < last; ++b) {
         uint64_t const key = shadow_key(uint32_t(col), d.rowI[b]);
         float* v = d.v3 + size_t(b) * E;
-        for (int e = threadIdx.x; e < E; e += 256) v[e] = shadow_value(key, uint32_t(e));
+        int const P = d.LM * d.LN;
+        for (int e = threadIdx.x; e < E; e += 256) {   // e = logical element [Re|Im][row][column], stored where the plan's element order puts it
+            int const c = e / P, r = (e % P) / d.LN, q = e % d.LN;
+            v[c * P + plane_offset(d.ilv, r, q, d.LN)] = shadow_value(key, uint32_t(e));
+        }
     }
 }
 

@@ -124,25 +124,28 @@ tfqmrgpuStatus_t analyse(Plan& p, int mb,
     }
 
     // ---- compress the block columns of X (tfqmrgpu.cu:254-315) ------------------------------
-    int32_t lo = 2147483647, hi = -2147483647;
-    for (int q = 0; q < nnzbX; ++q) { lo = std::min(lo, colIndX[q]); hi = std::max(hi, colIndX[q]); }
+    // The reference histograms the range [min, max] of the column indices and numbers the non-empty columns in ascending
+    // order; the same numbering from a sorted list of the distinct indices, so that one stray index cannot ask for 2^32 counters.
+    std::vector<int32_t> distinct(colIndX, colIndX + nnzbX);
+    std::sort(distinct.begin(), distinct.end());
+    distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+    int32_t const lo = distinct.front(), hi = distinct.back();
     int64_t const nc = int64_t(hi) - lo + 1;
-    if (nc < 1) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
     if (echo > 5) std::printf("# tfqmrgpu_bsrsv_createPlan: column indices of X are in [%d, %d]\n", lo, hi);
-    std::vector<uint32_t> perCol(nc, 0);
-    for (int q = 0; q < nnzbX; ++q) ++perCol[colIndX[q] - lo];
-    std::vector<int32_t> jc2jb(nc, -1);
-    uint32_t nb = 0, nempty = 0;
-    for (int64_t jc = 0; jc < nc; ++jc) { if (perCol[jc]) jc2jb[jc] = int32_t(nb++); else ++nempty; }
-    if (echo > 5) std::printf("# tfqmrgpu_bsrsv_createPlan: found %u empty columns and %u columns with entries\n", nempty, nb);
-    if (nempty > 0 && echo > 0) std::printf("# tfqmrgpu_bsrsv_createPlan: found %u empty columns in X!\n", nempty);
+    uint32_t const nb = uint32_t(distinct.size());
+    int64_t const nempty = nc - int64_t(nb);
+    if (echo > 5) std::printf("# tfqmrgpu_bsrsv_createPlan: found %lld empty columns and %u columns with entries\n", (long long)nempty, nb);
+    if (nempty > 0 && echo > 0) std::printf("# tfqmrgpu_bsrsv_createPlan: found %lld empty columns in X!\n", (long long)nempty);
     if (nb < 1) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    // the compressed column index is 16 bit in the reference (colIndex_t, tfqmrgpu.hxx:59; asserted at tfqmrgpu_core.hxx:81)
+    // and in this library's plan view and operator callback: more block columns are refused, not silently truncated
+    if (nb > 65536u) return TFQ_ERR(TFQMRGPU_NO_IMPLEMENTATION);
     p.nCols = nb;
     p.colindx.resize(nnzbX);
     p.col32.resize(nnzbX);
     p.original_bsrColIndX.assign(nb, 0);
     for (int q = 0; q < nnzbX; ++q) {
-        auto const jb = uint32_t(jc2jb[colIndX[q] - lo]);
+        auto const jb = uint32_t(std::lower_bound(distinct.begin(), distinct.end(), colIndX[q]) - distinct.begin());
         p.original_bsrColIndX[jb] = colIndX[q];
         p.colindx[q] = uint16_t(jb);   // the reference's colIndex_t is 16 bit (tfqmrgpu.hxx:59)
         p.col32[q] = jb;
@@ -226,6 +229,10 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     p.realBytes = ('z' == precision) ? 8 : 4;
     size_t const blockElems = size_t(2) * LM * LN;
     p.S = size_t(p.nnzbX) * blockElems * p.realBytes;
+    // row-pair-interleaved element order where the multiply kernel is written for it: 16 x 16 complex<double>
+    // (TFQMRGPU_ILV=0 keeps the native order everywhere, for A/B runs)
+    static int const ilvEnv = [] { auto v = std::getenv("TFQMRGPU_ILV"); return v ? std::atoi(v) : 1; }();
+    p.ilv = (ilvEnv && 16 == LM && 16 == LN && 'z' == precision) ? 1 : 0;
 
     // chunks: runs of CH blocks inside one column, sized so that a chunk of one vector is 8..16 KiB and the
     // grid has a few thousand work groups when the problem is large enough

@@ -36,6 +36,7 @@ struct Handle {
     int nranks = 1, rank = 0;
     tfqmrgpuReduceMax_t reduceFn = nullptr;
     void* reduceCtx = nullptr;
+    double* voteBuf = nullptr;            // 4 doubles of device memory for the collective in front of a solve (RCCL path)
 };
 
 struct Plan {
@@ -70,6 +71,7 @@ struct Plan {
     size_t realBytes = 0;              // 4 or 8
     size_t S = 0;                      // bytes of one X-shaped vector
     size_t bufferBytes = 0;
+    int ilv = 0;                       // element order inside the blocks of this plan's buffer (tfq_device.hpp: ilv_offset)
 
     // windows into the user's device buffer
     Window wX, wV4, wV5, wV6, wV7, wV8, wV9, wV3, wB, wA;

@@ -7,6 +7,7 @@
 // replica of A and its own pair list; only the stopping test couples the ranks.
 #include <algorithm>
 #include <cstdlib>
+#include <new>
 #include <vector>
 
 #include "tfq_plan.hpp"
@@ -19,6 +20,7 @@ extern "C" tfqmrgpuStatus_t tfqmrgpuExt_shardColumns(int mb,
     using namespace tfq;
     if (!shard || !rowPtrX || !colIndX || !rowPtrB || (nnzbB > 0 && !colIndB)) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
     if (mb < 1 || nnzbX < 1 || nranks < 1 || rank < 0 || rank >= nranks) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+    try {   // (no exception may cross the C boundary)
     int const off = indexOffset;
     // compressed columns exactly as createPlan numbers them: ascending original index, empty ones skipped
     std::vector<int32_t> cols(colIndX, colIndX + nnzbX);
@@ -71,6 +73,7 @@ extern "C" tfqmrgpuStatus_t tfqmrgpuExt_shardColumns(int mb,
         return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED);
     }
     return TFQMRGPU_STATUS_SUCCESS;
+    } catch (std::bad_alloc const&) { return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED); }
 }
 
 extern "C" void tfqmrgpuExt_freeShard(tfqmrgpuShard_t* shard) {

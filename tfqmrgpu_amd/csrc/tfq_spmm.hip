@@ -47,6 +47,7 @@ struct SpmmArgs {
     void const* Yext; uint32_t const* yPerm;   // k_spmm_direct only: take block y of the product from Yext[yPerm[y]]
     int hashV3;                        // the shadow vector is the counter-based hash (tfq_device.hpp): recompute it, do not read it
     int32_t const* origCol; uint32_t const* rowI;   // original block column per compressed column, block row per Y block
+    int ilv;                           // element order of the plan's blocks (tfq_device.hpp: ilv_offset); the plain mode is always native
 };
 
 // data that a kernel touches once (epilogue vectors) moves non-temporally, so that the stream does not push the A and
@@ -195,7 +196,8 @@ __global__ __launch_bounds__(256) void k_spmm_direct(SpmmArgs a) {
 #pragma unroll
         for (int n = 0; n < NACC; ++n) {
             int const e = e0 + n * 256;
-            epilogue<R, EPI>(a, size_t(y) * 2 * P + e, P, yr[n], yi[n], sr, si, bq, e, part);
+            int const el = plane_offset(a.ilv, e / LN, e % LN, LN);      // where the plan keeps element (row, column)
+            epilogue<R, EPI>(a, size_t(y) * 2 * P + el, P, yr[n], yi[n], sr, si, bq, el, part);
         }
     }
 
@@ -551,6 +553,161 @@ __global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at leas
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 16 x 16 complex<double> on the ROW-PAIR-INTERLEAVED element order (tfq_device.hpp: plane[r/2][s][r%2] for every block of
+// the plan, A blocks with r = k): the structure of k_spmm_mfma (one wave owns the 16 x 16 strip of a Y block in MFMA
+// accumulators, two operand register sets, epilogue operands requested behind the first two block products), but every
+// access is 16 bytes per lane -- one wave instruction moves 1 KiB instead of 512 bytes:
+//   k-steps: lane group lr = lane / 16 loads the k pairs lr and lr + 4, i.e. k = 2 lr, 2 lr + 1, 2 lr + 8, 2 lr + 9 feed the
+//            four MFMA steps of a block product (which k a step contracts is free as long as A and X agree);
+//   rows:    lane column a supplies A row rowp(a) = 2 (a % 4 + 4 (a / 8)) + (a / 4) % 2, so that the accumulator registers
+//            (0, 1) and (2, 3) of lane group lr are the row pairs (2 lr, 2 lr + 1), (2 lr + 8, 2 lr + 9) of column lane % 16:
+//            the epilogue reads and writes them as two 16-byte accesses per vector and plane.
+// Measured on P2 against k_spmm_mfma on the native order (same box, scripts/lab, profiles/r02_lab.txt): fused multiplies
+// 0.684 / 0.660 -> 0.628 / 0.595 ms.  The sums of a block product run over k in another order than in the native kernel
+// (results differ in the last bits, within the tolerances of the parity tests).
+__device__ inline int ilv_rowp(int a) { return 2 * ((a & 3) + 4 * (a >> 3)) + ((a >> 2) & 1); }
+using d2v = __attribute__((ext_vector_type(2))) double;
+using f2v = __attribute__((ext_vector_type(2))) float;
+
+template <int EPI, bool HASH>
+__global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
+    if (gate_closed(a)) return;
+    using R = double;
+    constexpr int LN = 16, P = 256, NPL = EpiPlanes<EPI>::N;
+    constexpr bool UPD = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
+    using T4 = d4;
+    int const lane = threadIdx.x & 63;
+    int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int const lr = lane >> 4, lc = lane & 15;
+    // the index lists through the constant address space: uniform reads become scalar loads whatever the stores around them
+    using CU32 = __attribute__((address_space(4))) uint32_t const*;
+    CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
+    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;   // XCD-aware launch order (tfq_plan.cpp)
+    uint32_t const first = a.chunkFirst[chunk], last = a.chunkFirst[chunk + 1], col = a.chunkCol[chunk];
+    R sr = 0, si = 0;
+    if constexpr (UPD) { sr = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + lc]; si = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + lc]; }
+    double part[NPL > 0 ? NPL : 1] = {};
+    __shared__ double s[4][NPL > 0 ? NPL : 1][LN];
+
+    struct Ops { d2v ar[2], ai[2], xr[2], xi[2]; };   // [k pair lr | lr + 4]
+    R const* const A0 = (R const*)a.A + (lr * 16 + ilv_rowp(lc)) * 2;
+    R const* const X0 = (R const*)a.X + (lr * 16 + lc) * 2;
+    auto fetch = [&](Ops& o, uint32_t q) __attribute__((always_inline)) {
+        R const* Ab = A0 + size_t(pairs[2 * size_t(q)]) * 2 * P;
+        R const* Xb = X0 + size_t(pairs[2 * size_t(q) + 1]) * 2 * P;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            o.ar[h] = *(d2v const*)(Ab + h * 128); o.ai[h] = *(d2v const*)(Ab + P + h * 128);
+            o.xr[h] = *(d2v const*)(Xb + h * 128); o.xi[h] = *(d2v const*)(Xb + P + h * 128);
+        }
+    };
+    for (uint32_t u = wave; u < last - first; u += 4) {
+        uint32_t const y = first + u;
+        uint64_t const key = HASH ? shadow_key(uint32_t(a.origCol[col]), a.rowI[y]) : 0;
+        T4 cre = T4{0, 0, 0, 0}, cim = T4{0, 0, 0, 0};
+        auto mma = [&](Ops const& o) __attribute__((always_inline)) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    R const nai = -o.ai[h][e];
+                    cre = Acc<R>::mma(o.ar[h][e], o.xr[h][e], cre);
+                    cim = Acc<R>::mma(o.ar[h][e], o.xi[h][e], cim);
+                    cre = Acc<R>::mma(nai, o.xi[h][e], cre);
+                    cim = Acc<R>::mma(o.ai[h][e], o.xr[h][e], cim);
+                }
+        };
+        uint32_t const q0 = starts[y], q1 = starts[y + 1];
+        Ops o0, o1;
+        if (q0 < q1) fetch(o0, q0);
+        if (q0 + 1 < q1) fetch(o1, q0 + 1);
+        // this lane's elements of the Y block: rows (2 lr, 2 lr + 1) and (2 lr + 8, 2 lr + 9) of column lc
+        int const eb[2] = { (lr * 16 + lc) * 2, ((lr + 4) * 16 + lc) * 2 };
+        size_t const yoff = size_t(y) * 2 * P;
+        d2v ur[2], ui[2], vr[2], vi[2]; f2v wr[2], wi[2];
+        if constexpr (UPD) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {   // old v4 | v5, v8, v3: touched once, non-temporal
+                ur[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff + eb[h])); ui[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff + eb[h] + P));
+                if constexpr (EPI == EPI_XPAY_DOT) { vr[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff + eb[h])); vi[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff + eb[h] + P)); }
+                if constexpr (!HASH) { wr[h] = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff + eb[h])); wi[h] = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff + eb[h] + P)); }
+            }
+        }
+        uint32_t q = q0;
+        for (; q + 2 <= q1; q += 2) {
+            mma(o0);
+            if (q + 2 < q1) fetch(o0, q + 2);
+            mma(o1);
+            if (q + 3 < q1) fetch(o1, q + 3);
+        }
+        if (q < q1) mma(o0);
+
+        uint32_t bq = 0xffffffffu;
+        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            d2v yr, yi, nr, ni;
+            d2v br = d2v{0, 0}, bi = d2v{0, 0};
+            if constexpr (EPI == EPI_RESIDUAL) if (bq != 0xffffffffu) {
+                R const* b = (R const*)a.B + size_t(bq) * 2 * P;
+                br = *(d2v const*)(b + eb[h]); bi = *(d2v const*)(b + eb[h] + P);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                yr[e] = cre[2 * h + e]; yi[e] = cim[2 * h + e];
+                // explicit fused multiply-adds: the HASH and the v3-reading instance of this kernel must round alike
+                // (tests/test_gpu_hash_mode.py compares them bit by bit), whatever the compiler would contract on its own
+                if constexpr (EPI == EPI_XPAY_DOT) {         // v9 := A v6; v4 := v8 + beta v4; v4 := v9 + beta v4 (tfqmrgpu_core.hxx:196-202)
+                    R const tr = __builtin_fma(-si, ui[h][e], __builtin_fma(sr, ur[h][e], vr[h][e]));
+                    R const ti = __builtin_fma(sr, ui[h][e], __builtin_fma(si, ur[h][e], vi[h][e]));
+                    nr[e] = __builtin_fma(-si, ti, __builtin_fma(sr, tr, yr[e]));
+                    ni[e] = __builtin_fma(sr, ti, __builtin_fma(si, tr, yi[e]));
+                } else if constexpr (EPI == EPI_AXPY_NRM_DOT) { // v8 := A v6; v5 := alfa v8 + v5 (tfqmrgpu_core.hxx:224-228)
+                    nr[e] = __builtin_fma(-si, yi[e], __builtin_fma(sr, yr[e], ur[h][e]));
+                    ni[e] = __builtin_fma(sr, yi[e], __builtin_fma(si, yr[e], ui[h][e]));
+                }
+                if constexpr (UPD) {
+                    int const row = 2 * (lr + 4 * h) + e;       // the logical element (row, lc): what the shadow vector's hash is defined on
+                    double w0, w1;
+                    if constexpr (HASH) { w0 = shadow_value(key, uint32_t(row * LN + lc)); w1 = shadow_value(key, uint32_t(P + row * LN + lc)); }
+                    else { w0 = wr[h][e]; w1 = wi[h][e]; }
+                    double const dr = nr[e], di = ni[e];
+                    part[0] = __builtin_fma(-di, w1, __builtin_fma(dr, w0, part[0]));
+                    part[1] = __builtin_fma(di, w0, __builtin_fma(dr, w1, part[1]));
+                    if constexpr (EPI == EPI_AXPY_NRM_DOT) part[2] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[2]));
+                } else if constexpr (EPI == EPI_RESIDUAL) {     // |A x - b|^2, nothing stored (tfqmrgpu_core.hxx:265-269)
+                    R const rr = yr[e] + R(-1) * br[e], ri = yi[e] + R(-1) * bi[e];
+                    double const dr = rr, di = ri;
+                    part[0] += dr * dr + di * di;
+                }
+            }
+            if constexpr (EPI != EPI_RESIDUAL) {
+                __builtin_nontemporal_store(yr, (d2v*)((R*)a.Y + yoff + eb[h])); __builtin_nontemporal_store(yi, (d2v*)((R*)a.Y + yoff + eb[h] + P));
+            }
+            if constexpr (UPD) {
+                __builtin_nontemporal_store(nr, (d2v*)((R*)a.e0 + yoff + eb[h])); __builtin_nontemporal_store(ni, (d2v*)((R*)a.e0 + yoff + eb[h] + P));
+            }
+        }
+    }
+    if constexpr (NPL > 0) {
+        // rows live on lane / 16 (and registers): add the four lane groups, then the four waves in order
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+            double v = part[p];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) s[wave][p][lane] = v;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < NPL * LN; e += 256) {
+            int const p = e / LN, j = e % LN;
+            double const sum = ((s[0][p][j] + s[1][p][j]) + s[2][p][j]) + s[3][p][j];
+            write_record<EPI>(a, chunk, LN, p, j, sum);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // MFMA kernel for 8-row blocks (LM == 8, LN % 8 == 0).  A 16x16 tile would be half empty, so the tile is
 // filled with the complex structure instead:   [Re A]             [Re A Re X | Re A Im X]
 //                                               [Im A] (16 x 8)  x  [Re X | Im X] (8 x 16)  =  [Im A Re X | Im A Im X]
@@ -784,6 +941,13 @@ template <typename R, int LM, int LN> constexpr bool kTile8 = (LM == 8) || (LM =
 template <typename R, int LM, int LN, int EPI>
 static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
     if (0 == nWG) return;
+    if constexpr (LM == 16 && LN == 16 && sizeof(R) == 8 && EPI != EPI_NONE) {
+        if (a.ilv) {   // the plan keeps its blocks row-pair-interleaved (tfq_plan.cpp: layoutBuffer)
+            if (a.hashV3 && EPI != EPI_RESIDUAL) k_spmm_ilv16<EPI, true><<<dim3(nWG), dim3(256), 0, s>>>(a);
+            else k_spmm_ilv16<EPI, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
+            return;
+        }
+    }
     if constexpr (LM % 16 == 0 && LN % 16 == 0) {
         // epilogue operands prefetched under the MFMAs where the registers allow it (one 16-column tile in double, two in float)
         constexpr bool pre = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) && ((LN / 16) * sizeof(R) <= 8);
@@ -849,7 +1013,7 @@ static SpmmArgs spmm_args(int epi, DevPlan const& d) {
     a.chunkFirst = d.chunkFirst; a.chunkCol = d.chunkCol; a.CH = 0;
     a.order = d.order;
     a.ctl = d.ctl; a.v3 = d.v3; a.B = d.B; a.bOfX = d.bOfX; a.pz = d.pz; a.pd = d.pd;
-    a.hashV3 = d.hashV3; a.origCol = d.origCol; a.rowI = d.rowI;
+    a.hashV3 = d.hashV3; a.origCol = d.origCol; a.rowI = d.rowI; a.ilv = d.ilv;
     switch (epi) {
     case EPI_XPAY_DOT:     a.X = d.v6; a.Y = d.v9; a.e0 = d.v4; a.e1 = d.v8; a.sc = d.beta; a.gate = 1; break;
     case EPI_AXPY_NRM_DOT: a.X = d.v6; a.Y = d.v8; a.e0 = d.v5; a.sc = d.alfa; a.gate = 1; break;

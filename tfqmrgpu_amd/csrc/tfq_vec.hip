@@ -67,10 +67,11 @@ template <int N> __device__ inline void ldf(float (&r)[N], float const* p) {
 template <typename R, int LN, int VEC>
 struct Scal {
     R re[VEC], im[VEC];
-    __device__ inline void load(R const* a, uint32_t col, int t) {
+    // ilv: the elements of an item are consecutive ROWS of one column (tfq_device.hpp: ilv_offset), else consecutive columns
+    __device__ inline void load(R const* a, uint32_t col, int t, int ilv = 0) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            int const j = (t * VEC + v) % LN;
+            int const j = ilv ? ((t * VEC + v) >> 1) % LN : (t * VEC + v) % LN;
             re[v] = a[(size_t(col) * 2 + 0) * LN + j];
             im[v] = a[(size_t(col) * 2 + 1) * LN + j];
         }
@@ -93,7 +94,7 @@ template <typename R> __device__ inline void axpy(R& yr, R& yi, R xr, R xi, R ar
 // Sum the per-thread accumulators of a work group into out[NPL][LN] (one record per chunk).
 // Fixed order => bitwise reproducible.  s is LDS of NPL*256*VEC doubles.
 template <int LN, int VEC, int T, int NPL>
-__device__ inline void chunk_reduce(double (&acc)[NPL][VEC], double* s, double* out, int t) {
+__device__ inline void chunk_reduce(double (&acc)[NPL][VEC], double* s, double* out, int t, int ilv = 0) {
     __syncthreads();
     if (t < T) {
 #pragma unroll
@@ -106,6 +107,9 @@ __device__ inline void chunk_reduce(double (&acc)[NPL][VEC], double* s, double* 
     for (int e = t; e < NPL * LN; e += 256) {
         int const p = e / LN, j = e % LN;
         double sum = 0;
+        if (ilv) {   // element m of the work group's slice belongs to column (m / 2) % LN: pairs of rows, then the next column
+            for (int n = 0; n < terms / 2; ++n) sum += s[p * (256 * VEC) + (n * LN + j) * 2] + s[p * (256 * VEC) + (n * LN + j) * 2 + 1];
+        } else
         for (int n = 0; n < terms; ++n) sum += s[p * (256 * VEC) + n * LN + j];
         out[p * LN + j] = sum;
     }
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256) void k_dot35(DevPlan d) {
             acc[1][v] += xr * yi + xi * yr;
         }
     }
-    chunk_reduce<LN, G::VEC, G::T, 2>(acc, s, d.pz + size_t(chunk) * 2 * LN, t);
+    chunk_reduce<LN, G::VEC, G::T, 2>(acc, s, d.pz + size_t(chunk) * 2 * LN, t, d.ilv);
 }
 
 // ---- KA: v6 := v5 + beta v6 ------------------------------------------------------------------------
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void k_xpay_v6(DevPlan d) {
     TFQ_CHUNK_PROLOGUE(G)
     if (t >= G::T) return;
     R const* v5 = (R const*)d.v5; R* v6 = (R*)d.v6;
-    Scal<R, LN, G::VEC> beta; beta.load((R const*)d.beta, col, t);
+    Scal<R, LN, G::VEC> beta; beta.load((R const*)d.beta, col, t, d.ilv);
     for (uint32_t w = t; w < nItems; w += G::T) {
         TFQ_ITEM_OFFSETS(G)
         R xr[G::VEC], xi[G::VEC], yr[G::VEC], yi[G::VEC];
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void k_v5_nrm(DevPlan d) {
     R* v5 = (R*)d.v5; R const* v9 = (R const*)d.v9;
     double acc[1][G::VEC] = {};
     if (t < G::T) {
-        Scal<R, LN, G::VEC> alfa; alfa.load((R const*)d.alfa, col, t);
+        Scal<R, LN, G::VEC> alfa; alfa.load((R const*)d.alfa, col, t, d.ilv);
         for (uint32_t w = t; w < nItems; w += G::T) {
             TFQ_ITEM_OFFSETS(G)
             R ar[G::VEC], ai[G::VEC], br[G::VEC], bi[G::VEC];
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256) void k_v5_nrm(DevPlan d) {
             stv(v5 + re, br); stv(v5 + im, bi);
         }
     }
-    chunk_reduce<LN, G::VEC, G::T, 1>(acc, s, d.pd + size_t(chunk) * LN, t);
+    chunk_reduce<LN, G::VEC, G::T, 1>(acc, s, d.pd + size_t(chunk) * LN, t, d.ilv);
 }
 
 // ---- KD: [x += eta2 v7 (left over from the previous iteration)] ; v7 := v6 + c67a v7 ; x += eta v7 ;
@@ -207,8 +211,8 @@ __global__ __launch_bounds__(256) void k_x_v6_v7(DevPlan d) {
     bool const pend = (d.ctl->xpend != 0);
     R* x = (R*)d.x; R* v6 = (R*)d.v6; R* v7 = (R*)d.v7; R const* v4 = (R const*)d.v4;
     Scal<R, LN, G::VEC> eta, eta2, alfa, c67, c67a;
-    eta.load((R const*)d.eta, col, t); eta2.load((R const*)d.eta2, col, t); alfa.load((R const*)d.alfa, col, t);
-    c67.load((R const*)d.c67, col, t); c67a.load((R const*)d.c67a, col, t);
+    eta.load((R const*)d.eta, col, t, d.ilv); eta2.load((R const*)d.eta2, col, t, d.ilv); alfa.load((R const*)d.alfa, col, t, d.ilv);
+    c67.load((R const*)d.c67, col, t, d.ilv); c67a.load((R const*)d.c67a, col, t, d.ilv);
     for (uint32_t w = t; w < nItems; w += G::T) {
         TFQ_ITEM_OFFSETS(G)
         R sr[G::VEC], si[G::VEC], xr[G::VEC], xi[G::VEC], ar[G::VEC], ai[G::VEC], br[G::VEC], bi[G::VEC];
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(256) void k_x_flush(DevPlan d) {
     TFQ_CHUNK_PROLOGUE(G)
     if (t >= G::T) return;
     R* x = (R*)d.x; R const* v7 = (R const*)d.v7;
-    Scal<R, LN, G::VEC> eta; eta.load((R const*)d.eta2, col, t);
+    Scal<R, LN, G::VEC> eta; eta.load((R const*)d.eta2, col, t, d.ilv);
     for (uint32_t w = t; w < nItems; w += G::T) {
         TFQ_ITEM_OFFSETS(G)
         R sr[G::VEC], si[G::VEC], xr[G::VEC], xi[G::VEC];
@@ -436,10 +440,11 @@ __global__ __launch_bounds__(256) void k_decide(DevPlan d, int what, int phase) 
             if (t < h) { if (s0[t + h] > s0[t]) s0[t] = s0[t + h]; if (s1[t + h] > s1[t]) s1[t] = s1[t + h]; }
             __syncthreads();
         }
-        if (0 == t) { c->red[2 * what] = s0[0]; c->red[2 * what + 1] = s1[0]; }
+        if (0 == t) { c->red[3 * what] = s0[0]; c->red[3 * what + 1] = s1[0]; }   // red[3 * what + 2] is the host's: "this rank failed"
         __syncthreads();
     }
     if (phase == 1 || t != 0) return;
+    if (c->red[3 * what + 2] > 0.) { c->state = 4; c->probe = 0; return; }   // some rank failed: every rank stops at this very slot
     if (0 == what) {
         int const it = ++c->iteration;
         double const bound2 = c->red[0] * (2 * it + 1);
@@ -450,13 +455,13 @@ __global__ __launch_bounds__(256) void k_decide(DevPlan d, int what, int phase) 
         c->xpend = 1;   // x += eta2 v7 of this iteration is still outstanding
     } else {
         double max_res2 = 1.4e-76;
-        if (c->red[2] > max_res2) max_res2 = c->red[2];
+        if (c->red[3] > max_res2) max_res2 = c->red[3];
         c->residual2_reached = max_res2;
         c->target_bound2 = (c->max_bound2 / max_res2) * c->tol2;
         c->nprobes += 1;
         c->probe = 0;
         c->xpend = 0;   // k_x_flush has brought x up to date
-        if (c->red[3] == 0.) { c->iterations_needed = c->iteration; c->state = 1; }
+        if (c->red[4] == 0.) { c->iterations_needed = c->iteration; c->state = 1; }
         else if (c->iteration >= c->maxIterations) c->state = 3;
     }
 }
@@ -485,7 +490,8 @@ __global__ __launch_bounds__(256) void k_init_col(DevPlan d, double tol, int max
     if (g < G) for (uint32_t q = d.bColPtr[col]; q < d.bColPtr[col + 1]; ++q) { // blocks of B in column order
         R const* b = (R const*)d.B + size_t(d.bList[q]) * 2 * P;
         for (int i = g; i < LM; i += G) {
-            double const r = b[i * LN + j], im = b[P + i * LN + j];
+            int const e = plane_offset(d.ilv, i, j, LN);
+            double const r = b[e], im = b[P + e];
             acc += r * r + im * im;
         }
     }
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(256) void k_init_col(DevPlan d, double tol, int max
         Ctl* c = d.ctl;
         double const tol2 = tol * tol;
         c->tol2 = tol2; c->target_bound2 = tol2 * 100 * 100; c->max_bound2 = 0; c->residual2_reached = 1e300;
-        c->red[0] = c->red[1] = c->red[2] = c->red[3] = 0;
+        for (int i = 0; i < 6; ++i) c->red[i] = 0;
         c->iteration = 0; c->maxIterations = maxIterations;
         c->state = (maxIterations > 0) ? 0 : 3;
         c->probe = 0; c->iterations_needed = maxIterations; c->nprobes = 0; c->xpend = 0;
@@ -518,13 +524,13 @@ __global__ __launch_bounds__(256) void k_init_col(DevPlan d, double tol, int max
     X(R, 16, 16) X(R, 16, 32) X(R, 16, 64) X(R, 32, 32) X(R, 32, 64) X(R, 64, 64)
 
 template <typename R, int LM, int LN>
-static void vec_run(int op, DevPlan const& d, double tol, int maxIt, hipStream_t s) {
+static hipError_t vec_run(int op, DevPlan const& d, double tol, int maxIt, hipStream_t s) {
     dim3 const grid(d.nChunks), cols(d.nCols), blk(256);
     switch (op) {
     case VEC_SETUP: {
         size_t const S = size_t(d.nnzbX) * 2 * LM * LN * sizeof(R);
         // x, v4..v9 are contiguous in the buffer (x first): clear them with one async memset
-        (void)hipMemsetAsync(d.x, 0, size_t((char*)d.v9 - (char*)d.x) + S, s);
+        if (auto const e = hipMemsetAsync(d.x, 0, size_t((char*)d.v9 - (char*)d.x) + S, s)) return e;
         if (d.nnzbB) k_scatter_B<R, LM, LN><<<dim3(d.nnzbB), blk, 0, s>>>(d);
         k_init_col<R, LM, LN><<<cols, blk, 0, s>>>(d, tol, maxIt);
         k_dot35<R, LM, LN><<<grid, blk, 0, s>>>(d);
@@ -539,14 +545,16 @@ static void vec_run(int op, DevPlan const& d, double tol, int maxIt, hipStream_t
     case VEC_X_FLUSH:  k_x_flush<R, LM, LN><<<grid, blk, 0, s>>>(d); break;
     case VEC_PROBE_COL: k_probe_col<LN><<<cols, blk, 0, s>>>(d); break;
     }
+    return hipSuccess;   // launch errors are sticky: run_solve collects them with hipGetLastError
 }
 
-void vec_launch(int op, DevPlan const& d, double tol, int maxIt, hipStream_t s) {
+hipError_t vec_launch(int op, DevPlan const& d, double tol, int maxIt, hipStream_t s) {
     int const key = d.LM * 1000 + d.LN;
-#define TFQ_CASE(R, LM, LN) case LM * 1000 + LN: vec_run<R, LM, LN>(op, d, tol, maxIt, s); break;
+#define TFQ_CASE(R, LM, LN) case LM * 1000 + LN: return vec_run<R, LM, LN>(op, d, tol, maxIt, s);
     if (d.dbl) { switch (key) { TFQ_SIZES(TFQ_CASE, double) default: break; } }
     else       { switch (key) { TFQ_SIZES(TFQ_CASE, float)  default: break; } }
 #undef TFQ_CASE
+    return hipErrorInvalidValue;
 }
 
 void launch_decide(DevPlan const& d, int phase, hipStream_t s)       { k_decide<<<1, 256, 0, s>>>(d, 0, phase); }

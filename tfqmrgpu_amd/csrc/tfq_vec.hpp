@@ -17,7 +17,7 @@ enum {
     VEC_PROBE_COL      // per-column residual record from pd
 };
 
-void vec_launch(int op, DevPlan const& d, double tol, int maxIt, hipStream_t s);
+hipError_t vec_launch(int op, DevPlan const& d, double tol, int maxIt, hipStream_t s);   // the runtime call of VEC_SETUP may fail
 
 // Y = A*X over the plan's pair list with a fused epilogue (EPI_* in tfq_device.hpp)
 void spmm_launch(int epi, DevPlan const& d, hipStream_t s);
