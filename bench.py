@@ -92,6 +92,10 @@ def kernel_model(pr, prec, nPairs, nA_ref):
     }
 
 
+def S_bytes(pr, prec):
+    return pr.nnzbX * 2 * pr.LM * pr.LN * (8 if prec == "z" else 4)
+
+
 def roof(bytes_, flops, ms, prec):
     peak_f = MFMA_PEAK_TFLOPS["f64" if prec == "z" else "f32"]
     t_b, t_f = bytes_ / (HBM_PEAK_GBS * 1e9), flops / (peak_f * 1e12)
@@ -285,7 +289,25 @@ def main():
                 rl["traffic"] = json.load(open(tp)).get(args.workload, {}).get(dom)
                 rl["traffic_source"] = "profiles/pmc_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE of scripts/pmc_collect.sh, kept from the latest PMC run; not measured in this run)"
 
-            # the stand-alone multiply on the same pair list (what the reference times in `bench_tfqmrgpu multi`)
+            # The BSR multiply Y = A*X on its own, twice:
+            #  roofline_multiply            on the plan's data with the solver's kernel and element order (tfqmrgpuExt_applyOperator)
+            #  roofline_multiply_native_api on caller-owned arrays in the reference's native order (tfqmrgpuExt_multiply: the
+            #                               contract of the reference's gemmNxNf, what its `bench_tfqmrgpu multi` times)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+            def timed(fn, reps):
+                fn()
+                e0.record(stream)
+                fn(reps)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / reps
+            s.set_matrix("X", (np.random.default_rng(1).uniform(-1, 1, (pr.nnzbX, pr.LM, pr.LN)) + 0j)) if pr.nnzbX * pr.LM * pr.LN < 5e7 else None
+            copy_ms = 2 * S_bytes(pr, prec) / 5.5e9 / max(1, args.multiply_reps)      # the one vector copy behind the repetitions, at ~5.5 TB/s
+            mms = timed(lambda reps=1: s.apply_operator(reps), args.multiply_reps) - copy_ms
+            rm = roof(model["multiply"][0], model["multiply"][1], mms, prec)
+            rm.update(kernel="multiply on the plan's data (Y = A*X, no epilogue, solver's kernel and element order)", avg_ms=round(mms, 5),
+                      launches=args.multiply_reps, algorithmic_bytes=int(model["multiply"][0]), algorithmic_flops=float(model["multiply"][1]))
             real = torch.float64 if prec == "z" else torch.float32
             An = torch.from_numpy(np.ascontiguousarray(np.stack([pr.A.transpose(0, 2, 1).real, pr.A.transpose(0, 2, 1).imag], axis=1))).to(real).cuda()
             Xn = torch.rand((pr.nnzbX, 2, pr.LM, pr.LN), dtype=real, device="cuda") * 2 - 1
@@ -293,62 +315,39 @@ def main():
             dS = torch.from_numpy(view["starts"].view(np.int32)).cuda()
             dP = torch.from_numpy(view["pairs"].view(np.int32)).cuda()
 
-            def mult():
-                T._check(T.lib.tfqmrgpuExt_multiply(s.handle, prec.encode(), pr.LM, pr.LN, pr.nnzbX, dS.data_ptr(), dP.data_ptr(),
-                                                    An.data_ptr(), Xn.data_ptr(), Yn.data_ptr()), "tfqmrgpuExt_multiply")
-            for _ in range(3):
-                mult()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for _ in range(args.multiply_reps):
-                mult()
-            e1.record(stream)
-            torch.cuda.synchronize()
-            mms = e0.elapsed_time(e1) / args.multiply_reps
-            rm = roof(model["multiply"][0], model["multiply"][1], mms, prec)
-            rm.update(kernel="multiply (Y = A*X, no epilogue)", avg_ms=round(mms, 5), launches=args.multiply_reps,
-                      algorithmic_bytes=int(model["multiply"][0]), algorithmic_flops=float(model["multiply"][1]))
+            def mult(reps=1):
+                for _ in range(reps):
+                    T._check(T.lib.tfqmrgpuExt_multiply(s.handle, prec.encode(), pr.LM, pr.LN, pr.nnzbX, dS.data_ptr(), dP.data_ptr(),
+                                                        An.data_ptr(), Xn.data_ptr(), Yn.data_ptr()), "tfqmrgpuExt_multiply")
+            mult(2)
+            mms_n = timed(mult, args.multiply_reps)
+            rmn = roof(model["multiply"][0], model["multiply"][1], mms_n, prec)
+            rmn.update(kernel="multiply on caller-owned native arrays (tfqmrgpuExt_multiply)", avg_ms=round(mms_n, 5), launches=args.multiply_reps)
+            del An, Xn, Yn
 
-            # the HBM-bound corner of the same multiply kernel: the operator applied to ONE block column, every A block
-            # used once (arithmetic intensity 5.8 flop/B for 16x16 z, ridge 9.8).  Index lists of a 5-point block stencil
-            # on a 384 x 384 grid, values random on the device.
+            # the HBM-bound corner of the multiply: the operator applied to ONE block column, every A block used once
+            # (arithmetic intensity 5.8 flop/B for 16x16 z, ridge 9.8): 5-point block stencil on a 256 x 256 grid, its own plan
             rh = None
             if prec == "z" and pr.LM == 16 and pr.LN == 16 and not args.no_hbm_multiply:
-                n1 = 384
-                ix, iy = np.meshgrid(np.arange(n1), np.arange(n1), indexing="ij")
-                rows, nbr = [], []
-                for dx, dy in ((0, 0), (1, 0), (-1, 0), (0, 1), (0, -1)):
-                    ok = (ix + dx >= 0) & (ix + dx < n1) & (iy + dy >= 0) & (iy + dy < n1)
-                    rows.append((ix * n1 + iy)[ok]); nbr.append(((ix + dx) * n1 + iy + dy)[ok])
-                rows, nbr = np.concatenate(rows), np.concatenate(nbr)
-                o = np.argsort(rows, kind="stable")
-                rows, nbr = rows[o], nbr[o]
-                nY1, nP1 = n1 * n1, len(rows)
-                st1 = np.zeros(nY1 + 1, np.int64); np.add.at(st1, rows + 1, 1); st1 = np.cumsum(st1).astype(np.uint32)
-                pa1 = np.stack([np.arange(nP1), nbr], axis=1).astype(np.uint32).reshape(-1)
-                A1 = torch.rand((nP1, 2, 16, 16), dtype=real, device="cuda") - 0.5
-                X1 = torch.rand((nY1, 2, 16, 16), dtype=real, device="cuda") - 0.5
-                Y1 = torch.empty_like(X1)
-                dS1, dP1 = torch.from_numpy(st1.view(np.int32)).cuda(), torch.from_numpy(pa1.view(np.int32)).cuda()
-
-                def mult1():
-                    T._check(T.lib.tfqmrgpuExt_multiply(s.handle, b"z", 16, 16, nY1, dS1.data_ptr(), dP1.data_ptr(),
-                                                        A1.data_ptr(), X1.data_ptr(), Y1.data_ptr()), "tfqmrgpuExt_multiply")
-                for _ in range(5):
-                    mult1()
-                e0.record(stream)
-                for _ in range(args.multiply_reps):
-                    mult1()
-                e1.record(stream)
-                torch.cuda.synchronize()
-                ms1 = e0.elapsed_time(e1) / args.multiply_reps
+                from tfqmrgpu_amd import problems as PR
+                p1 = PR.stencil_2d(256, 256, 16, 16, 1, seed=11)
+                s1 = T.Solver(stream.cuda_stream)
+                s1.create_plan(p1)
+                v1 = s1.plan_view()
+                buf1 = torch.empty(s1.buffer_size(16, 16, "z"), dtype=torch.uint8, device="cuda")
+                s1.set_buffer(device_ptr=buf1.data_ptr())
+                s1.set_matrix("A", p1.A)
+                s1.set_matrix("X", np.random.default_rng(2).uniform(-1, 1, (p1.nnzbX, 16, 16)) + 0j)
+                ms1 = timed(lambda reps=1: s1.apply_operator(reps), args.multiply_reps) - 2 * S_bytes(p1, "z") / 5.5e9 / max(1, args.multiply_reps)
+                nP1, nY1 = v1["nPairs"], p1.nnzbX
                 b1 = (nP1 + 2 * nY1) * 2 * 16 * 16 * 8 + 4 * (nY1 + 1) + 8 * nP1
                 f1 = nP1 * 8.0 * 16 * 16 * 16
                 rh = dict(bound="hbm", achieved=round(b1 / (ms1 * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                           frac=round(b1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), tflops=round(f1 / (ms1 * 1e-3) / 1e12, 3),
-                          kernel="multiply, operator on one block column (5-point block stencil 384x384, every A block used once)",
+                          kernel="multiply on the plan's data, operator on ONE block column (5-point block stencil 256x256, every A block used once)",
                           avg_ms=round(ms1, 5), launches=args.multiply_reps, algorithmic_bytes=int(b1), algorithmic_flops=f1)
-                del A1, X1, Y1
+                s1.close()
+                del buf1
 
             S = pr.nnzbX * 2 * pr.LM * pr.LN * (8 if prec == "z" else 4)
             it_bytes = sum(model[k][0] for k in ("xpay_v6", "spmm_v4_dot", "v5_nrm", "x_v6_v7", "spmm_v5_nrm_dot"))
@@ -373,6 +372,7 @@ def main():
                 "roofline_dominant": rl_dominant,
                 "roofline_kernels": rl_all,
                 "roofline_multiply": rm,
+                "roofline_multiply_native_api": rmn,
                 "roofline_multiply_hbm_bound": rh,
                 "roofline_iteration": dict(bound="hbm", achieved=round(it_bytes / (it_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                                            frac=round(it_bytes / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), ms_per_iteration=round(it_ms, 4),

@@ -85,6 +85,13 @@ tfqmrgpuStatus_t tfqmrgpuExt_multiply(tfqmrgpuHandle_t handle,
     uint32_t nnzbY, uint32_t const *starts_d, uint32_t const *pairs_d,
     void const *A_d, void const *X_d, void *Y_d);
 
+/* The same product on the data of a plan: X := A * X for the plan's operator A (as given to setMatrix('A')) and the
+ * plan's X (setMatrix('X') before, getMatrix('X') afterwards), truncated to the pattern of X like every product of the
+ * solver.  Uses the multiply kernel and the block / element order of the solver itself -- for 16 x 16
+ * complex<double> plans the row-pair-interleaved one -- so it is also what bench.py times as "the BSR multiply".
+ * `repetitions` > 1 computes the product that many times from the same X (timing); asynchronous on the handle's stream. */
+tfqmrgpuStatus_t tfqmrgpuExt_applyOperator(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, int repetitions);
+
 /* ---- (4) multi-GPU: one process per GPU, block columns of X/B sharded ------------------- */
 /* Splits the compressed block columns of X into `nranks` contiguous ranges with balanced
  * block counts and extracts the sub-patterns of X and B that belong to `rank`.

@@ -503,3 +503,29 @@ def test_random_ragged_systems(oracle):
             assert info["iterations"] == info0["iterations"], (case, LM, LN)
             Xd = PR.dense_reference_solution(pr)
             assert np.abs(X - Xd).max() <= 1e-8 * np.abs(Xd).max(), (case, LM, LN)
+
+
+@pytest.mark.parametrize("prec", ["z", "c"])
+@pytest.mark.parametrize("shape", [(16, 16), (8, 8), (4, 5), (32, 32), (16, 64)])
+def test_apply_operator_on_plan_data(oracle, prec, shape):
+    """X := A*X with the solver's own multiply kernel and block / element order (16 x 16 z: row pairs interleaved)
+    against the oracle's product on the caller's order (reference contract: tfqmrgpu_blockmult.hxx:9-93)"""
+    LM, LN = shape
+    pr = PR.stencil_2d(7, 5, LM, LN, 3, seed=LM + LN + 3, radius=3.1)
+    rng = np.random.default_rng(LM * LN)
+    X = rng.uniform(-1, 1, (pr.nnzbX, LM, LN)) + 1j * rng.uniform(-1, 1, (pr.nnzbX, LM, LN))
+    real = np.float64 if prec == "z" else np.float32
+    an = oracle.analyse(pr)
+    want = oracle.from_native(oracle.spmm(prec, LM, LN, an["starts"], an["pairs"], oracle.a_native(pr.A, real), oracle.to_native(X, real)))
+    with T.Solver() as s:
+        s.create_plan(pr)
+        s.set_buffer(nbytes=s.buffer_size(LM, LN, prec))
+        s.set_matrix("A", pr.A)
+        s.set_matrix("X", X)
+        s.apply_operator()
+        got = s.get_matrix()
+        s.set_matrix("X", X)
+        s.apply_operator(3)                       # repetitions start from the same X
+        assert np.array_equal(s.get_matrix(), got)
+    eps = 1e-13 if prec == "z" else 3e-5
+    assert np.abs(got - want).max() <= eps * LM * 6 * max(1.0, np.abs(want).max())

@@ -33,7 +33,7 @@ EXT_SYMBOLS = [  # include/tfqmrgpu_ext.h
     "tfqmrgpuExt_planView", "tfqmrgpuExt_getBoundHistory", "tfqmrgpuExt_setProfiling", "tfqmrgpuExt_getProfile",
     "tfqmrgpuExt_getProfileGated",
     "tfqmrgpuExt_setShadowMode",
-    "tfqmrgpuExt_setShadowVector", "tfqmrgpuExt_getShadowVector", "tfqmrgpuExt_multiply", "tfqmrgpuExt_shardColumns",
+    "tfqmrgpuExt_setShadowVector", "tfqmrgpuExt_getShadowVector", "tfqmrgpuExt_multiply", "tfqmrgpuExt_applyOperator", "tfqmrgpuExt_shardColumns",
     "tfqmrgpuExt_freeShard", "tfqmrgpuExt_commUniqueId", "tfqmrgpuExt_commInit",
     "tfqmrgpuExt_commDestroy", "tfqmrgpuExt_setReduceCallback", "tfqmrgpuExt_setOperator",
 ]
@@ -116,6 +116,7 @@ def load_library(path=LIB_PATH):
     lib.tfqmrgpuExt_setShadowVector.argtypes = [P, P, P]
     lib.tfqmrgpuExt_getShadowVector.argtypes = [P, P, P]
     lib.tfqmrgpuExt_multiply.argtypes = [P, C.c_char, I, I, C.c_uint32, P, P, P, P, P]
+    lib.tfqmrgpuExt_applyOperator.argtypes = [P, P, I]
     lib.tfqmrgpuExt_shardColumns.argtypes = [I, P, I, P, P, I, P, I, I, I, C.POINTER(Shard)]
     lib.tfqmrgpuExt_freeShard.argtypes = [C.POINTER(Shard)]
     lib.tfqmrgpuExt_freeShard.restype = None
@@ -264,6 +265,10 @@ class Solver:
             return out.reshape(nnzb, -1)
         c = out[..., 0] + 1j * out[..., 1]
         return c if trans in "n*" else c.reshape(nnzb, self.LN, self.LM)
+
+    def apply_operator(self, repetitions=1):
+        """X := A*X on the plan's data (tfqmrgpuExt_applyOperator)"""
+        return _check(lib.tfqmrgpuExt_applyOperator(self.handle, self.plan, repetitions), "tfqmrgpuExt_applyOperator")
 
     # -- solve -----------------------------------------------------------------------------------------
     def solve(self, threshold, max_iterations):

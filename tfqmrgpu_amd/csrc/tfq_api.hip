@@ -813,6 +813,19 @@ tfqmrgpuStatus_t tfqmrgpuExt_multiply(tfqmrgpuHandle_t handle, char precision, i
     return launch_multiply(precision, lm, ln, nnzbY, starts_d, pairs_d, A_d, X_d, Y_d, (hipStream_t)h->stream);
 }
 
+tfqmrgpuStatus_t tfqmrgpuExt_applyOperator(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, int repetitions) {
+    auto p = asPlan(plan); auto h = (Handle*)handle;
+    if (!p || !h || !p->buffer) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    if ('z' != p->precision && 'c' != p->precision) return err(TFQMRGPU_PRECISION_MISSMATCH, __LINE__ % 10000, p->precision);
+    if (p->opFn) return TFQ_ERR(TFQMRGPU_NO_IMPLEMENTATION);       // a user-defined operator is the caller's to apply
+    hipStream_t const s = (hipStream_t)h->stream;
+    DevPlan const d = resolve(*p);
+    for (int r = 0; r < std::max(1, repetitions); ++r) spmm_apply(d, d.x, d.v9, s);   // the work vector v9 is free outside of a solve
+    TFQ_HIP(hipMemcpyAsync(d.x, d.v9, p->S, hipMemcpyDeviceToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+    TFQ_HIP(hipGetLastError(), TFQMRGPU_STATUS_LAUNCH_FAILED)
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
 tfqmrgpuStatus_t tfqmrgpuExt_commUniqueId(char id[128]) {
     if (!id) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
     if (!g_rccl.load()) return TFQ_ERR(TFQMRGPU_NO_IMPLEMENTATION);

@@ -418,7 +418,12 @@ __device__ inline void epilogue_row(SpmmArgs const& a, size_t off, int P, R cons
     }
 }
 
-template <typename R, int LM, int LN, int EPI, bool PRE, bool M3, bool HASH>
+// CLAMP: the operand prefetch inside a strip carries no condition (the slice index is clamped to the last slice instead: two
+// redundant, cache-resident slice loads per strip), so that the compiler can count the loads in flight and waits for exactly the
+// slice it is about to multiply -- with the conditional form it drains the whole queue (s_waitcnt vmcnt(0)) in front of every
+// slice.  Used where a strip has many slices (blocks of 32 rows and more: the matrix-pipe-bound shapes).
+// NSET: operand register sets of the software pipeline (2, or 4 with CLAMP where a slice is small: the float shapes).
+template <typename R, int LM, int LN, int EPI, bool PRE, bool M3, bool HASH, bool CLAMP = false, int NSET = 2>
 __global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at least 2 waves per SIMD: 256 VGPRs at most
     if (gate_closed(a)) return;
     static_assert(LM % 16 == 0 && LN % 16 == 0, "MFMA tiles are 16 x 16");
@@ -470,15 +475,18 @@ __global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at leas
         auto mma = [&](Slice<R, MS, NT, KSL> const& o) __attribute__((always_inline)) {
             if constexpr (M3) o.mma3(cre, cim, cp3); else o.mma(cre, cim);
         };
-        uint32_t const q0 = a.starts[y];
-        uint32_t const nT = (a.starts[y + 1] - q0) * SPP;   // slices of this strip
+        // index lists through the constant address space: uniform reads stay scalar loads whatever the stores around them
+        using CU32 = __attribute__((address_space(4))) uint32_t const*;
+        CU32 const cstarts = (CU32)(uintptr_t)a.starts; CU32 const cpairs = (CU32)(uintptr_t)a.pairs;
+        uint32_t const q0 = cstarts[y];
+        uint32_t const nT = (cstarts[y + 1] - q0) * SPP;   // slices of this strip
         R const* const A0 = (R const*)a.A + i0 + lc * MS;
         R const* const X0 = (R const*)a.X + c0;
         auto fetch = [&](Slice<R, MS, NT, KSL>& o, uint32_t t) {
             uint32_t const q = q0 + t / SPP;
             int const k0 = int(t % SPP) * (4 * KSL);
-            o.template load<LM, LN>(A0 + size_t(a.pairs[2 * size_t(q)]) * 2 * LM * LM,
-                                    X0 + size_t(a.pairs[2 * size_t(q) + 1]) * 2 * P, k0, lr);
+            o.template load<LM, LN>(A0 + size_t(cpairs[2 * size_t(q)]) * 2 * LM * LM,
+                                    X0 + size_t(cpairs[2 * size_t(q) + 1]) * 2 * P, k0, lr);
         };
         // block row of accumulator register r of row tile ms
         auto row_of = [&](int ms, int r) { return i0 + Acc<R>::row(lane, r) * MS + ms; };
@@ -486,9 +494,17 @@ __global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at leas
         // of slice t issue.  With PRE the operands of the epilogue (old v4|v5, v8, v3) are requested right
         // behind the first two slices: vmcnt retires in order, so they must be younger than the slices
         // whose MFMAs should start first and they have two slices of matrix work to arrive.
-        Slice<R, MS, NT, KSL> o0, o1;
-        if (nT > 0) fetch(o0, 0);
-        if (nT > 1) fetch(o1, 1);
+        static_assert(NSET == 2 || CLAMP, "the deeper pipeline is written for the unconditional prefetch");
+        Slice<R, MS, NT, KSL> o[NSET];
+        if constexpr (CLAMP) {
+            if (nT > 0) {
+#pragma unroll
+                for (int i = 0; i < NSET; ++i) fetch(o[i], (uint32_t(i) < nT) ? uint32_t(i) : nT - 1);
+            }
+        } else {
+            if (nT > 0) fetch(o[0], 0);
+            if (nT > 1) fetch(o[1], 1);
+        }
         EpiOps<R, EPI, VW, HASH> ops[PRE ? MS * 4 * NG : 1];
         if constexpr (PRE) {
 #pragma unroll
@@ -500,13 +516,16 @@ __global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at leas
                         ops[(ms * 4 + r) * NG + g].load(a, size_t(y) * 2 * P + row_of(ms, r) * LN + c0 + g * 16 * VW, P);
         }
         uint32_t t = 0;
-        for (; t + 2 <= nT; t += 2) {
-            mma(o0);
-            if (t + 2 < nT) fetch(o0, t + 2);
-            mma(o1);
-            if (t + 3 < nT) fetch(o1, t + 3);
+        for (; t + NSET <= nT; t += NSET) {
+#pragma unroll
+            for (int i = 0; i < NSET; ++i) {
+                mma(o[i]);
+                uint32_t const tn = t + NSET + i;
+                if constexpr (CLAMP) fetch(o[i], (tn < nT) ? tn : nT - 1); else if (tn < nT) fetch(o[i], tn);
+            }
         }
-        if (t < nT) mma(o0);
+#pragma unroll
+        for (int i = 0; i < NSET - 1; ++i) if (t + i < nT) mma(o[i]);
 
         uint32_t bq = 0xffffffffu;
         if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
@@ -941,8 +960,8 @@ template <typename R, int LM, int LN> constexpr bool kTile8 = (LM == 8) || (LM =
 template <typename R, int LM, int LN, int EPI>
 static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
     if (0 == nWG) return;
-    if constexpr (LM == 16 && LN == 16 && sizeof(R) == 8 && EPI != EPI_NONE) {
-        if (a.ilv) {   // the plan keeps its blocks row-pair-interleaved (tfq_plan.cpp: layoutBuffer)
+    if constexpr (LM == 16 && LN == 16 && sizeof(R) == 8) {
+        if (a.ilv && a.chunkFirst) {   // the plan keeps its blocks row-pair-interleaved (tfq_plan.cpp: layoutBuffer); never the plain mode
             if (a.hashV3 && EPI != EPI_RESIDUAL) k_spmm_ilv16<EPI, true><<<dim3(nWG), dim3(256), 0, s>>>(a);
             else k_spmm_ilv16<EPI, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
             return;
@@ -965,8 +984,25 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
         constexpr bool canHash = (LN == 16) && (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
         bool const m3 = sizeof(R) == 8 && ((use_m3 && (LM / 16) * (LN / 16) >= 2) || use_m3 >= 2);   // TFQMRGPU_3M=2: 16 x 16 too (A/B runs)
         bool const p = pre && use_pre;
+        // unconditional (clamped) operand prefetch where a strip has at least 8 slices per block product (LM >= 32)
+        constexpr bool canClamp = (LM >= 32);
+        static int const use_clamp = [] { auto v = std::getenv("TFQMRGPU_CLAMP"); return v ? std::atoi(v) : 1; }();
+        // TFQMRGPU_DEEP=1: four operand sets for 32 x 32 float (measured on config 3: plain multiply 90.8 -> 94.8 TFLOP/s, but the
+        // fused kernel with its epilogue prefetch spills: 0.317 -> 0.350 ms) -- off by default
+        static int const use_deep = [] { auto v = std::getenv("TFQMRGPU_DEEP"); return v ? std::atoi(v) : 0; }();
         auto go = [&](auto M3c, auto Hc) {
             constexpr bool M3 = decltype(M3c)::value, H = decltype(Hc)::value;
+            if constexpr (canClamp) if (use_clamp) {
+                constexpr int NS = (sizeof(R) == 4 && LM == 32 && LN == 32) ? 4 : 2;   // four operand sets where they fit: 32 x 32 float (a slice is 16 registers)
+                if (NS == 4 && !use_deep) {
+                    if (p) k_spmm_mfma<R, LM, LN, EPI, pre, M3, H, true, 2><<<dim3(nWG), dim3(256), 0, s>>>(a);
+                    else k_spmm_mfma<R, LM, LN, EPI, false, M3, H, true, 2><<<dim3(nWG), dim3(256), 0, s>>>(a);
+                    return;
+                }
+                if (p) k_spmm_mfma<R, LM, LN, EPI, pre, M3, H, true, NS><<<dim3(nWG), dim3(256), 0, s>>>(a);
+                else k_spmm_mfma<R, LM, LN, EPI, false, M3, H, true, NS><<<dim3(nWG), dim3(256), 0, s>>>(a);
+                return;
+            }
             if (p) k_spmm_mfma<R, LM, LN, EPI, pre, M3, H><<<dim3(nWG), dim3(256), 0, s>>>(a);
             else k_spmm_mfma<R, LM, LN, EPI, false, M3, H><<<dim3(nWG), dim3(256), 0, s>>>(a);
         };
@@ -1026,6 +1062,13 @@ static SpmmArgs spmm_args(int epi, DevPlan const& d) {
 void spmm_launch(int epi, DevPlan const& d, hipStream_t s) {
     if (epi != EPI_XPAY_DOT && epi != EPI_AXPY_NRM_DOT && epi != EPI_RESIDUAL) return;
     spmm_dispatch(d.dbl, d.LM, d.LN, epi, spmm_args(epi, d), d.nChunks, s);
+}
+
+// Y = A * X on vectors of the plan (both in the plan's own block and element order), no epilogue, never gated
+void spmm_apply(DevPlan const& d, void const* X, void* Y, hipStream_t s) {
+    SpmmArgs a = spmm_args(EPI_NONE, d);
+    a.X = X; a.Y = Y; a.gate = 0;
+    spmm_dispatch(d.dbl, d.LM, d.LN, EPI_NONE, a, d.nChunks, s);
 }
 
 template <typename R, int LM, int LN>

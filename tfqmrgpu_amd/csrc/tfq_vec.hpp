@@ -22,6 +22,9 @@ hipError_t vec_launch(int op, DevPlan const& d, double tol, int maxIt, hipStream
 // Y = A*X over the plan's pair list with a fused epilogue (EPI_* in tfq_device.hpp)
 void spmm_launch(int epi, DevPlan const& d, hipStream_t s);
 
+// Y = A*X on two X-shaped vectors of the plan, no epilogue (tfqmrgpuExt_applyOperator)
+void spmm_apply(DevPlan const& d, void const* X, void* Y, hipStream_t s);
+
 // the epilogue of spmm_launch alone, for a product Y that a user-defined operator has already written:
 // Yext holds the blocks in the caller's order, i2u[internal block] = caller's block
 void epilogue_launch(int epi, DevPlan const& d, void const* Yext, uint32_t const* i2u, hipStream_t s);
