@@ -117,10 +117,10 @@ def main():
             variant, n, np.diff(first).max(), np.diff(first).mean(), 100.0 * inside.mean()))
 
     ident = np.arange(pr.mb)
-    for G in (8, 16):
-        emit("baseg%d" % G, ident, ident * 0, 4, G)
-    emit("base8", ident, ident * 0, 8)
-    emit("base", ident, ident * 0, 4)          # cluster = row: chunks cut every 4 blocks (the product's 16 KiB chunks for 16x16 z)
+    emit("base", ident, ident * 0, 4)
+    if os.environ.get("LAB_BASE_ONLY"):
+        return
+         # cluster = row: chunks cut every 4 blocks (the product's 16 KiB chunks for 16x16 z)
     emit("line16", ident, ident // csize, csize)
     cl, order = clusters_of(adj, csize)
     rank = np.empty(pr.mb, np.int64); rank[order] = np.arange(pr.mb)

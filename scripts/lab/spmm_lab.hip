@@ -822,7 +822,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_v6(SpmmArgs a) {
     CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
     uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;
     uint32_t const first = a.chunkFirst[chunk], last = a.chunkFirst[chunk + 1], col = a.chunkCol[chunk];
-    R const sr = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + lc], si = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + lc];
+    R const sr = (EPI == EPI_NONE) ? 0 : ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + lc], si = (EPI == EPI_NONE) ? 0 : ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + lc];
     double part[NPL > 0 ? NPL : 1] = {};
     __shared__ double s[4][3][LN];
 
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_v6(SpmmArgs a) {
         size_t const eoff[2] = { size_t(y) * 2 * P + (lr * 16 + lc) * 2, size_t(y) * 2 * P + ((lr + 4) * 16 + lc) * 2 };
         d2v ur[2], ui[2], xr[2], xi[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < 2; ++h) if constexpr (EPI != EPI_NONE) {
             ur[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + eoff[h])); ui[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + eoff[h] + P));
             if constexpr (EPI == EPI_XPAY_DOT) { xr[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + eoff[h])); xi[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + eoff[h] + P)); }
         }
@@ -881,6 +881,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_v6(SpmmArgs a) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 yr[e] = cre[2 * h + e]; yi[e] = cim[2 * h + e];
+                if constexpr (EPI == EPI_NONE) continue;
                 if constexpr (EPI == EPI_XPAY_DOT) {
                     R const tr = xr[h][e] + sr * ur[h][e] - si * ui[h][e], ti = xi[h][e] + si * ur[h][e] + sr * ui[h][e];
                     nr[e] = yr[e] + sr * tr - si * ti; ni[e] = yi[e] + si * tr + sr * ti;
@@ -895,7 +896,113 @@ __global__ __launch_bounds__(256, 2) void k_spmm_v6(SpmmArgs a) {
                 if constexpr (EPI == EPI_AXPY_NRM_DOT) part[2] += dr * dr + di * di;
             }
             __builtin_nontemporal_store(yr, (d2v*)((R*)a.Y + eoff[h])); __builtin_nontemporal_store(yi, (d2v*)((R*)a.Y + eoff[h] + P));
-            __builtin_nontemporal_store(nr, (d2v*)((R*)a.e0 + eoff[h])); __builtin_nontemporal_store(ni, (d2v*)((R*)a.e0 + eoff[h] + P));
+            if constexpr (EPI != EPI_NONE) { __builtin_nontemporal_store(nr, (d2v*)((R*)a.e0 + eoff[h])); __builtin_nontemporal_store(ni, (d2v*)((R*)a.e0 + eoff[h] + P)); }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+        double v = part[p];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 16) s[wave][p][lane] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NPL * LN; e += 256) {
+        int const p = e / LN, j = e % LN;
+        double const sum = ((s[0][p][j] + s[1][p][j]) + s[2][p][j]) + s[3][p][j];
+        write_record<EPI>(a, chunk, LN, p, j, sum);
+    }
+}
+
+template <int EPI, bool HASH, int ANT>
+__global__ __launch_bounds__(256, 2) void k_spmm_v6nt(SpmmArgs a) {
+    if (gate_closed(a)) return;
+    using R = double;
+    constexpr int LM = 16, LN = 16, P = 256, NPL = EpiPlanes<EPI>::N;
+    using T4 = d4;
+    int const lane = threadIdx.x & 63;
+    int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int const lr = lane >> 4, lc = lane & 15;
+    using CU32 = __attribute__((address_space(4))) uint32_t const*;
+    CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
+    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    uint32_t const first = a.chunkFirst[chunk], last = a.chunkFirst[chunk + 1], col = a.chunkCol[chunk];
+    R const sr = (EPI == EPI_NONE) ? 0 : ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + lc], si = (EPI == EPI_NONE) ? 0 : ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + lc];
+    double part[NPL > 0 ? NPL : 1] = {};
+    __shared__ double s[4][3][LN];
+
+    struct Ops { d2v ar[2], ai[2], xr[2], xi[2]; };   // [k-pair lr | lr + 4]
+    // element offsets of this lane: A (k-pair kp, row ROWP(lc)), X (k-pair kp, column lc)
+    R const* const A0 = (R const*)a.A + (lr * 16 + rowp(lc)) * 2;
+    R const* const X0 = (R const*)a.X + (lr * 16 + lc) * 2;
+    auto fetch = [&](Ops& o, uint32_t q) __attribute__((always_inline)) {
+        R const* Ab = A0 + size_t(pairs[2 * size_t(q)]) * 2 * P;
+        R const* Xb = X0 + size_t(pairs[2 * size_t(q) + 1]) * 2 * P;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            o.ar[h] = __builtin_nontemporal_load((d2v const*)(Ab + h * 128)); o.ai[h] = __builtin_nontemporal_load((d2v const*)(Ab + P + h * 128));
+            if (ANT > 1) { o.xr[h] = __builtin_nontemporal_load((d2v const*)(Xb + h * 128)); o.xi[h] = __builtin_nontemporal_load((d2v const*)(Xb + P + h * 128)); }
+            else { o.xr[h] = *(d2v const*)(Xb + h * 128); o.xi[h] = *(d2v const*)(Xb + P + h * 128); }
+        }
+    };
+    for (uint32_t u = wave; u < last - first; u += 4) {
+        uint32_t const y = first + u;
+        uint64_t const key = HASH ? shadow_key(uint32_t(a.origCol[col]), a.rowI[y]) : 0;
+        T4 cre = T4{0, 0, 0, 0}, cim = T4{0, 0, 0, 0};
+        auto mma = [&](Ops const& o) __attribute__((always_inline)) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    R const nai = -o.ai[h][e];
+                    cre = Acc<R>::mma(o.ar[h][e], o.xr[h][e], cre);
+                    cim = Acc<R>::mma(o.ar[h][e], o.xi[h][e], cim);
+                    cre = Acc<R>::mma(nai, o.xi[h][e], cre);
+                    cim = Acc<R>::mma(o.ai[h][e], o.xr[h][e], cim);
+                }
+        };
+        uint32_t const q0 = starts[y], q1 = starts[y + 1];
+        Ops o0, o1;
+        if (q0 < q1) fetch(o0, q0);
+        if (q0 + 1 < q1) fetch(o1, q0 + 1);
+        // epilogue operands: row pairs (2 lr, 2 lr + 1) and (2 lr + 8, 2 lr + 9) of column lc, 16 bytes each
+        size_t const eoff[2] = { size_t(y) * 2 * P + (lr * 16 + lc) * 2, size_t(y) * 2 * P + ((lr + 4) * 16 + lc) * 2 };
+        d2v ur[2], ui[2], xr[2], xi[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) if constexpr (EPI != EPI_NONE) {
+            ur[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + eoff[h])); ui[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + eoff[h] + P));
+            if constexpr (EPI == EPI_XPAY_DOT) { xr[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + eoff[h])); xi[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + eoff[h] + P)); }
+        }
+        uint32_t q = q0;
+        for (; q + 2 <= q1; q += 2) {
+            mma(o0);
+            if (q + 2 < q1) fetch(o0, q + 2);
+            mma(o1);
+            if (q + 3 < q1) fetch(o1, q + 3);
+        }
+        if (q < q1) mma(o0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            d2v yr, yi, nr, ni;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                yr[e] = cre[2 * h + e]; yi[e] = cim[2 * h + e];
+                if constexpr (EPI == EPI_NONE) continue;
+                if constexpr (EPI == EPI_XPAY_DOT) {
+                    R const tr = xr[h][e] + sr * ur[h][e] - si * ui[h][e], ti = xi[h][e] + si * ur[h][e] + sr * ui[h][e];
+                    nr[e] = yr[e] + sr * tr - si * ti; ni[e] = yi[e] + si * tr + sr * ti;
+                } else {
+                    nr[e] = sr * yr[e] - si * yi[e] + ur[h][e]; ni[e] = si * yr[e] + sr * yi[e] + ui[h][e];
+                }
+                int const row = 2 * (lr + 4 * h) + e;                    // logical element (row, lc) for the shadow vector
+                double const wr = shadow_value(key, uint32_t(row * LN + lc)), wi = shadow_value(key, uint32_t(P + row * LN + lc));
+                double const dr = nr[e], di = ni[e];
+                part[0] += dr * wr - di * wi;
+                part[1] += dr * wi + di * wr;
+                if constexpr (EPI == EPI_AXPY_NRM_DOT) part[2] += dr * dr + di * di;
+            }
+            __builtin_nontemporal_store(yr, (d2v*)((R*)a.Y + eoff[h])); __builtin_nontemporal_store(yi, (d2v*)((R*)a.Y + eoff[h] + P));
+            if constexpr (EPI != EPI_NONE) { __builtin_nontemporal_store(nr, (d2v*)((R*)a.e0 + eoff[h])); __builtin_nontemporal_store(ni, (d2v*)((R*)a.e0 + eoff[h] + P)); }
         }
     }
 #pragma unroll
@@ -1084,7 +1191,7 @@ __global__ __launch_bounds__(256, WPS) void k_spmm_v8(SpmmArgs a) {
     uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;
     uint32_t const first = a.chunkFirst[chunk], last = a.chunkFirst[chunk + 1], col = a.chunkCol[chunk];
     uint32_t const nb = last - first;
-    R const sr = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + lc], si = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + lc];
+    R const sr = (EPI == EPI_NONE) ? 0 : ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + lc], si = (EPI == EPI_NONE) ? 0 : ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + lc];
     double part[NPL > 0 ? NPL : 1] = {};
     __shared__ double s[4][3][LN];
 
@@ -1134,7 +1241,7 @@ __global__ __launch_bounds__(256, WPS) void k_spmm_v8(SpmmArgs a) {
         size_t const eoff[2] = { size_t(y) * 2 * P + (lr * 16 + lc) * 2, size_t(y) * 2 * P + ((lr + 4) * 16 + lc) * 2 };
         d2v ur[2], ui[2], vr[2], vi[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < 2; ++h) if constexpr (EPI != EPI_NONE) {
             ur[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + eoff[h])); ui[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + eoff[h] + P));
             if constexpr (EPI == EPI_XPAY_DOT) { vr[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + eoff[h])); vi[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + eoff[h] + P)); }
         }
@@ -1159,6 +1266,7 @@ __global__ __launch_bounds__(256, WPS) void k_spmm_v8(SpmmArgs a) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 yr[e] = cre[2 * h + e]; yi[e] = cim[2 * h + e];
+                if constexpr (EPI == EPI_NONE) continue;
                 if constexpr (EPI == EPI_XPAY_DOT) {
                     R const tr = vr[h][e] + sr * ur[h][e] - si * ui[h][e], ti = vi[h][e] + si * ur[h][e] + sr * ui[h][e];
                     nr[e] = yr[e] + sr * tr - si * ti; ni[e] = yi[e] + si * tr + sr * ti;
@@ -1173,7 +1281,7 @@ __global__ __launch_bounds__(256, WPS) void k_spmm_v8(SpmmArgs a) {
                 if constexpr (EPI == EPI_AXPY_NRM_DOT) part[2] += dr * dr + di * di;
             }
             __builtin_nontemporal_store(yr, (d2v*)((R*)a.Y + eoff[h])); __builtin_nontemporal_store(yi, (d2v*)((R*)a.Y + eoff[h] + P));
-            __builtin_nontemporal_store(nr, (d2v*)((R*)a.e0 + eoff[h])); __builtin_nontemporal_store(ni, (d2v*)((R*)a.e0 + eoff[h] + P));
+            if constexpr (EPI != EPI_NONE) { __builtin_nontemporal_store(nr, (d2v*)((R*)a.e0 + eoff[h])); __builtin_nontemporal_store(ni, (d2v*)((R*)a.e0 + eoff[h] + P)); }
         }
     }
 #pragma unroll
@@ -1276,15 +1384,17 @@ int main(int argc, char** argv) {
     SpmmArgs ai = a; ai.A = Ai; ai.X = v6i; ai.Y = v9i; ai.e0 = v4i; ai.e1 = v8i;
     auto launch = [&](std::string const& v) {
         dim3 const g{uint32_t(nChunks)}, b{256};
-        if (v == "v0") { if (epi == 1) k_spmm_mfma<double, 16, 16, EPI_XPAY_DOT, true, false, true><<<g, b>>>(a); else k_spmm_mfma<double, 16, 16, EPI_AXPY_NRM_DOT, true, false, true><<<g, b>>>(a); }
+        if (v == "v0") { if (epi == 0) k_spmm_mfma<double, 16, 16, EPI_NONE, false, false, false><<<g, b>>>(a); else if (epi == 1) k_spmm_mfma<double, 16, 16, EPI_XPAY_DOT, true, false, true><<<g, b>>>(a); else k_spmm_mfma<double, 16, 16, EPI_AXPY_NRM_DOT, true, false, true><<<g, b>>>(a); }
         else if (v == "v2") { if (maxChunk > 16) { printf("v2 needs chunks of at most 16 blocks\n"); exit(1); }
                               if (epi == 1) k_spmm_ldsx<EPI_XPAY_DOT, true, 16, 4, 0><<<g, b>>>(a, dIn); else k_spmm_ldsx<EPI_AXPY_NRM_DOT, true, 16, 4, 0><<<g, b>>>(a, dIn); }
         else if (v == "v3") { if (maxChunk > 16) { printf("needs chunks of at most 16 blocks\n"); exit(1); } if (epi == 1) k_spmm_v3<EPI_XPAY_DOT, true, 16, 2, 4><<<g, b>>>(a, dIn); else k_spmm_v3<EPI_AXPY_NRM_DOT, true, 16, 2, 4><<<g, b>>>(a, dIn); }
         else if (v == "v4") { if (maxChunk > 16) { printf("needs chunks of at most 16 blocks\n"); exit(1); } if (epi == 1) k_spmm_v4<EPI_XPAY_DOT, true, 16, 2, 4><<<g, b>>>(a, dIn); else k_spmm_v4<EPI_AXPY_NRM_DOT, true, 16, 2, 4><<<g, b>>>(a, dIn); }
-        else if (v == "v6") { if (epi == 1) k_spmm_v6<EPI_XPAY_DOT, true><<<g, b>>>(ai); else k_spmm_v6<EPI_AXPY_NRM_DOT, true><<<g, b>>>(ai); }
+        else if (v == "v6") { if (epi == 0) k_spmm_v6<EPI_NONE, false><<<g, b>>>(ai); else if (epi == 1) k_spmm_v6<EPI_XPAY_DOT, true><<<g, b>>>(ai); else k_spmm_v6<EPI_AXPY_NRM_DOT, true><<<g, b>>>(ai); }
         else if (v == "v7") { if (maxChunk > 16) { printf("needs chunks of at most 16 blocks\n"); exit(1); } if (epi == 1) k_spmm_v7<EPI_XPAY_DOT, true, 16, 2, 4><<<g, b>>>(ai, dIn); else k_spmm_v7<EPI_AXPY_NRM_DOT, true, 16, 2, 4><<<g, b>>>(ai, dIn); }
         else if (v == "v7c12") { if (maxChunk > 12) { printf("needs chunks of at most 12 blocks\n"); exit(1); } if (epi == 1) k_spmm_v7<EPI_XPAY_DOT, true, 12, 2, 4, 3><<<g, b>>>(ai, dIn); else k_spmm_v7<EPI_AXPY_NRM_DOT, true, 12, 2, 4, 3><<<g, b>>>(ai, dIn); }
-        else if (v == "v8") { if (epi == 1) k_spmm_v8<EPI_XPAY_DOT, true, 3><<<g, b>>>(ai); else k_spmm_v8<EPI_AXPY_NRM_DOT, true, 3><<<g, b>>>(ai); }
+        else if (v == "v6nt") { if (epi == 0) k_spmm_v6nt<EPI_NONE, false, 1><<<g, b>>>(ai); else if (epi == 1) k_spmm_v6nt<EPI_XPAY_DOT, true, 1><<<g, b>>>(ai); else k_spmm_v6nt<EPI_AXPY_NRM_DOT, true, 1><<<g, b>>>(ai); }
+        else if (v == "v6nt2") { if (epi == 0) k_spmm_v6nt<EPI_NONE, false, 2><<<g, b>>>(ai); else if (epi == 1) k_spmm_v6nt<EPI_XPAY_DOT, true, 2><<<g, b>>>(ai); else k_spmm_v6nt<EPI_AXPY_NRM_DOT, true, 2><<<g, b>>>(ai); }
+        else if (v == "v8") { if (epi == 0) k_spmm_v8<EPI_NONE, false, 3><<<g, b>>>(ai); else if (epi == 1) k_spmm_v8<EPI_XPAY_DOT, true, 3><<<g, b>>>(ai); else k_spmm_v8<EPI_AXPY_NRM_DOT, true, 3><<<g, b>>>(ai); }
         else if (v == "v8w4") { if (epi == 1) k_spmm_v8<EPI_XPAY_DOT, true, 4><<<g, b>>>(ai); else k_spmm_v8<EPI_AXPY_NRM_DOT, true, 4><<<g, b>>>(ai); }
         else if (v == "v5") { if (maxChunk > 16) { printf("needs chunks of at most 16 blocks\n"); exit(1); } if (epi == 1) k_spmm_v5<EPI_XPAY_DOT, true, 16, 4, 2><<<g, b>>>(a, dIn); else k_spmm_v5<EPI_AXPY_NRM_DOT, true, 16, 4, 2><<<g, b>>>(a, dIn); }
         else if (v == "v5c12") { if (maxChunk > 12) { printf("needs chunks of at most 12 blocks\n"); exit(1); } if (epi == 1) k_spmm_v5<EPI_XPAY_DOT, true, 12, 4, 1, 3><<<g, b>>>(a, dIn); else k_spmm_v5<EPI_AXPY_NRM_DOT, true, 12, 4, 1, 3><<<g, b>>>(a, dIn); }
@@ -1333,7 +1443,7 @@ int main(int argc, char** argv) {
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms / reps);
         }
         std::sort(ts.begin(), ts.end());
-        double const bytes = (epi == 1 ? 5.0 : 4.0) * S * 8 + S * 4 + 72.04e6 + 4.0 * (nX + 1) + 8.0 * nP;
+        double const bytes = (epi == 0 ? 2.0 * S * 8 : (epi == 1 ? 5.0 : 4.0) * S * 8 + S * 4) + double(nA) * 4096 + 4.0 * (nX + 1) + 8.0 * nP;
         printf("%-6s epi %d: min %.4f ms median %.4f ms  (%.0f GB/s algorithmic, frac %.3f of 8 TB/s) | max|dY| %.2e of %.2e, max|dpz| %.2e of %.2e\n",
                v.c_str(), epi, ts[0], ts[2], bytes / ts[0] * 1e-6, bytes / ts[0] * 1e-6 / 8000, d9, m9, dz, mz);
         fflush(stdout);

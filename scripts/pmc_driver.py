@@ -15,6 +15,8 @@ view = s.plan_view()
 s.set_buffer(nbytes=s.buffer_size(pr.LM, pr.LN, prec))
 s.set_matrix("A", pr.A); s.set_matrix("B", pr.B)
 st = s.solve(1e-30, iters)
+s.set_matrix("X", np.random.default_rng(1).uniform(-1, 1, (pr.nnzbX, pr.LM, pr.LN)) + 0j)
+s.apply_operator(3)      # the multiply on the plan's data (solver's kernel and element order, EPI_NONE)
 real = torch.float64 if prec == "z" else torch.float32
 At = pr.A.transpose(0, 2, 1)
 An = torch.from_numpy(np.ascontiguousarray(np.stack([At.real, At.imag], axis=1))).to(real).cuda()

@@ -110,11 +110,12 @@ def test_recomputing_the_shadow_vector_changes_no_bit(tmp_path, name, prec, tol)
 
 SWITCHES = [dict(TFQMRGPU_3M=0), dict(TFQMRGPU_3M=2), dict(TFQMRGPU_EPI_PREFETCH=0), dict(TFQMRGPU_ORDER=0),
             dict(TFQMRGPU_DEPTH=1), dict(TFQMRGPU_DEPTH=4), dict(TFQMRGPU_CHUNK_KIB=64), dict(TFQMRGPU_ORDER_G=8),
-            dict(TFQMRGPU_ILV=0)]     # ILV=0: 16 x 16 z plans keep the native element order (k_spmm_mfma instead of k_spmm_ilv16)
+            dict(TFQMRGPU_ILV=0),     # ILV=0: 16 x 16 and 8 x 8 z plans keep the native element order (k_spmm_mfma / k_spmm_mfma8)
+            dict(TFQMRGPU_A_STREAM=0), dict(TFQMRGPU_CLAMP=0)]
 
 
 @pytest.mark.parametrize("name,prec,tol", [("stencil:16:16:16:16:4:7:5", "z", 1e-9), ("stencil:8:8:32:32:2:3:13", "z", 1e-9),
-                                           ("stencil:12:12:8:8:4:5:5", "z", 1e-9)])
+                                           ("stencil:12:12:8:8:4:5:5", "z", 1e-9), ("stencil:12:12:16:16:1:7:5", "z", 1e-9)])   # one block column: A streamed past the caches
 def test_tuning_switches_change_code_paths_not_results(tmp_path, name, prec, tol):
     """every non-default value of the environment switches: same status and iteration count, the
     solution within rounding (a switch may change the order of a sum: chunk length, three-product form)"""
@@ -125,5 +126,5 @@ def test_tuning_switches_change_code_paths_not_results(tmp_path, name, prec, tol
         assert int(got["status"]) == 0 and int(got["iterations"]) == int(base["iterations"]), sw
         assert np.allclose(got["history"], base["history"], rtol=1e-6, atol=0), sw
         assert np.abs(got["X"] - base["X"]).max() <= 1e-9 * np.abs(base["X"]).max(), sw
-        if "TFQMRGPU_DEPTH" in sw or "TFQMRGPU_ORDER" in sw or "TFQMRGPU_ORDER_G" in sw:
+        if "TFQMRGPU_DEPTH" in sw or "TFQMRGPU_ORDER" in sw or "TFQMRGPU_ORDER_G" in sw or "TFQMRGPU_A_STREAM" in sw:
             assert np.array_equal(got["X"], base["X"]), sw   # these change WHEN things run, never what is added to what

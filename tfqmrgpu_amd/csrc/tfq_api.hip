@@ -29,6 +29,8 @@ DevPlan resolve(Plan const& p) {
     static int const hashEnv = [] { auto v = std::getenv("TFQMRGPU_HASHV3"); return v ? std::atoi(v) : 1; }();
     d.hashV3 = (p.v3IsHash && hashEnv) ? 1 : 0;   // TFQMRGPU_HASHV3=0: the multiply kernels read v3 also in hash mode
     d.ilv = p.ilv;
+    static int const antEnv = [] { auto v = std::getenv("TFQMRGPU_A_STREAM"); return v ? std::atoi(v) : 1; }();
+    d.aOnce = (p.aOnce && antEnv) ? 1 : 0;   // TFQMRGPU_A_STREAM=0: A operands always through the caches
     d.x = at(p.wX); d.v4 = at(p.wV4); d.v5 = at(p.wV5); d.v6 = at(p.wV6); d.v7 = at(p.wV7);
     d.v8 = at(p.wV8); d.v9 = at(p.wV9); d.B = at(p.wB); d.A = at(p.wA); d.v3 = (float*)at(p.wV3);
     d.rho = at(p.wRho); d.alfa = at(p.wAlfa); d.beta = at(p.wBeta); d.c67 = at(p.wC67); d.eta = at(p.wEta);

@@ -37,6 +37,7 @@ struct DevPlan {
     uint32_t nCols, nnzbX, nnzbB, nnzbA, nChunks;
     int hashV3;                                // v3 holds the counter-based hash below: kernels may recompute instead of reading it
     int ilv;                                   // element order inside a block plane: 0 native [r][s], 1 row pairs interleaved (see ilv_offset)
+    int aOnce;                                 // a multiply uses every A block about once (<= 1.5 times): A is streamed, not cached
     void *x, *v4, *v5, *v6, *v7, *v8, *v9, *B, *A;
     float* v3;
     void *rho, *alfa, *beta, *c67, *eta;       // [nCols][2][LN] real

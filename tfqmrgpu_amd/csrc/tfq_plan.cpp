@@ -107,6 +107,12 @@ tfqmrgpuStatus_t analyse(Plan& p, int mb,
         }
     }
     p.pairs.shrink_to_fit();
+    {   // how often a multiply uses an A block on average (decides the cache policy of the A operands, tfq_spmm.hip)
+        std::vector<uint8_t> used(size_t(nnzbA), 0);
+        size_t distinctA = 0;
+        for (size_t q = 0; q < p.pairs.size(); q += 2) if (!used[p.pairs[q]]) { used[p.pairs[q]] = 1; ++distinctA; }
+        p.aOnce = (distinctA > 0) && (2 * p.nPairs() <= 3 * distinctA);
+    }
     if (echo > 6) std::printf("# tfqmrgpu_bsrsv_createPlan: found %zu pairs in A*X multiplication\n", p.nPairs());
 
     // ---- B must live on blocks of X (tfqmrgpu.cu:233-251) ---------------------------------------
@@ -229,10 +235,10 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     p.realBytes = ('z' == precision) ? 8 : 4;
     size_t const blockElems = size_t(2) * LM * LN;
     p.S = size_t(p.nnzbX) * blockElems * p.realBytes;
-    // row-pair-interleaved element order where the multiply kernel is written for it: 16 x 16 complex<double>
+    // row-pair-interleaved element order where the multiply kernel is written for it: 16 x 16 and 8 x 8 complex<double>
     // (TFQMRGPU_ILV=0 keeps the native order everywhere, for A/B runs)
     static int const ilvEnv = [] { auto v = std::getenv("TFQMRGPU_ILV"); return v ? std::atoi(v) : 1; }();
-    p.ilv = (ilvEnv && 16 == LM && 16 == LN && 'z' == precision) ? 1 : 0;
+    p.ilv = (ilvEnv && ((16 == LM && 16 == LN) || (8 == LM && 8 == LN && ilvEnv != 16)) && 'z' == precision) ? 1 : 0;   // TFQMRGPU_ILV=16: only 16 x 16
 
     // chunks: runs of CH blocks inside one column, sized so that a chunk of one vector is 8..16 KiB and the
     // grid has a few thousand work groups when the problem is large enough

@@ -71,6 +71,7 @@ struct Plan {
     size_t realBytes = 0;              // 4 or 8
     size_t S = 0;                      // bytes of one X-shaped vector
     size_t bufferBytes = 0;
+    bool aOnce = false;                // nPairs <= 1.5 x the A blocks that occur in the pair list: A is streamed once per multiply
     int ilv = 0;                       // element order inside the blocks of this plan's buffer (tfq_device.hpp: ilv_offset)
 
     // windows into the user's device buffer

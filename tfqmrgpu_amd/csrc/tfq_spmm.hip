@@ -48,6 +48,7 @@ struct SpmmArgs {
     int hashV3;                        // the shadow vector is the counter-based hash (tfq_device.hpp): recompute it, do not read it
     int32_t const* origCol; uint32_t const* rowI;   // original block column per compressed column, block row per Y block
     int ilv;                           // element order of the plan's blocks (tfq_device.hpp: ilv_offset); the plain mode is always native
+    int aOnce;                         // every A block is used about once per multiply (few block columns): stream A past the caches
 };
 
 // data that a kernel touches once (epilogue vectors) moves non-temporally, so that the stream does not push the A and
@@ -588,7 +589,11 @@ __device__ inline int ilv_rowp(int a) { return 2 * ((a & 3) + 4 * (a >> 3)) + ((
 using d2v = __attribute__((ext_vector_type(2))) double;
 using f2v = __attribute__((ext_vector_type(2))) float;
 
-template <int EPI, bool HASH>
+// ANT: the A operands are loaded non-temporally.  For an operator applied to one or two block columns every A block is used
+// once per multiply -- the kernel is a stream of A through HBM, and 16-byte non-temporal loads take it from 5.5 to 6.6 TB/s
+// (one block column, 1.3 GB of A: plain multiply 0.69 -> 0.82 of 8 TB/s, fused 0.76 -> 0.85, profiles/r02_lab.txt); with
+// many columns A is re-used out of the caches and must stay there (the plan decides: SpmmArgs::aOnce).
+template <int EPI, bool HASH, bool ANT = false>
 __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
     if (gate_closed(a)) return;
     using R = double;
@@ -616,7 +621,8 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
         R const* Xb = X0 + size_t(pairs[2 * size_t(q) + 1]) * 2 * P;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            o.ar[h] = *(d2v const*)(Ab + h * 128); o.ai[h] = *(d2v const*)(Ab + P + h * 128);
+            if constexpr (ANT) { o.ar[h] = __builtin_nontemporal_load((d2v const*)(Ab + h * 128)); o.ai[h] = __builtin_nontemporal_load((d2v const*)(Ab + P + h * 128)); }
+            else { o.ar[h] = *(d2v const*)(Ab + h * 128); o.ai[h] = *(d2v const*)(Ab + P + h * 128); }
             o.xr[h] = *(d2v const*)(Xb + h * 128); o.xi[h] = *(d2v const*)(Xb + P + h * 128);
         }
     };
@@ -722,6 +728,148 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
             int const p = e / LN, j = e % LN;
             double const sum = ((s[0][p][j] + s[1][p][j]) + s[2][p][j]) + s[3][p][j];
             write_record<EPI>(a, chunk, LN, p, j, sum);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 8 x 8 complex<double> on the row-pair-interleaved element order (BASELINE config 5: the bandwidth-bound shape).
+// A block is 1 KiB = ONE wave-wide 16-byte access: lane (lr = lane / 16, c = (lane % 16) / 8, j = lane % 8) holds the k pair lr
+// (k = 2 lr, 2 lr + 1) of plane c (Re | Im) and column j.  The matrix tile is filled like in k_spmm_mfma8:
+//      [Re A; Im A] (16 x 8)  x  [Re X | Im X] (8 x 16)  =  [Q00 Q01; Q10 Q11],   Y = (Q00 - Q11) + i (Q01 + Q10)
+// with the A rows supplied in the order pi(a) = 2 (a % 4) + a / 4, so that accumulator registers (0, 1) | (2, 3) of a lane are the
+// rows (2 lr, 2 lr + 1) of Q0c | Q1c: one exchange with the lane 8 further (the other plane) gives every lane one 16-byte piece
+// of Re Y (c = 0) or Im Y (c = 1) -- the Y block, each epilogue operand and each result are again ONE access per wave.
+// Per Y block: 2 loads per block product + 2 (3) epilogue loads + 2 stores, against 4 per product + 8 + 4 eight-byte accesses and
+// an LDS round trip in k_spmm_mfma8.
+__device__ inline double xor8(double v) { return __shfl_xor(v, 8); }
+__device__ inline d2v xor8(d2v v) { return d2v{__shfl_xor(v[0], 8), __shfl_xor(v[1], 8)}; }
+
+template <int EPI, bool HASH>
+__global__ __launch_bounds__(256) void k_spmm_ilv8(SpmmArgs a) {
+    if (gate_closed(a)) return;
+    using R = double;
+    constexpr int LN = 8, P = 64, NPL = EpiPlanes<EPI>::N;
+    constexpr bool UPD = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
+    using T4 = d4;
+    int const lane = threadIdx.x & 63;
+    int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int const lr = lane >> 4, lc = lane & 15, cp = lc >> 3, j = lc & 7;
+    using CU32 = __attribute__((address_space(4))) uint32_t const*;
+    CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
+    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    uint32_t const first = a.chunkFirst[chunk], last = a.chunkFirst[chunk + 1], col = a.chunkCol[chunk];
+    R sr = 0, si = 0;
+    if constexpr (UPD) { sr = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + j]; si = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + j]; }
+    double part[NPL > 0 ? NPL : 1] = {};
+    __shared__ double s[4][NPL > 0 ? NPL : 1][LN];
+
+    int const mine = cp * P + (lr * 8 + j) * 2;                                 // this lane's 16 bytes of an X-shaped block
+    R const* const A0 = (R const*)a.A + cp * P + (lr * 8 + 2 * (j & 3) + (j >> 2)) * 2;   // A: row pi(j) of plane cp, k pair lr
+    R const* const X0 = (R const*)a.X + mine;
+    struct Ops { d2v av, xv; };
+    auto fetch = [&](Ops& o, uint32_t q) __attribute__((always_inline)) {
+        o.av = *(d2v const*)(A0 + size_t(pairs[2 * size_t(q)]) * 2 * P);
+        o.xv = *(d2v const*)(X0 + size_t(pairs[2 * size_t(q) + 1]) * 2 * P);
+    };
+    for (uint32_t u = wave; u < last - first; u += 4) {
+        uint32_t const y = first + u;
+        uint64_t const key = HASH ? shadow_key(uint32_t(a.origCol[col]), a.rowI[y]) : 0;
+        T4 acc = T4{0, 0, 0, 0};
+        uint32_t const q0 = starts[y], nq = starts[y + 1] - q0;
+        constexpr int DEPTH = 4;
+        Ops o[DEPTH];
+#pragma unroll
+        for (int dd = 0; dd < DEPTH; ++dd) if (uint32_t(dd) < nq) fetch(o[dd], q0 + dd);
+        size_t const yoff = size_t(y) * 2 * P + mine;
+        d2v uM = d2v{0, 0}, vM = d2v{0, 0}; f2v wM = f2v{0, 0};
+        if constexpr (UPD) {                       // the epilogue operands travel while the products are computed
+            uM = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff));
+            if constexpr (EPI == EPI_XPAY_DOT) vM = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff));
+            if constexpr (!HASH) wM = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff));
+        }
+        for (uint32_t base = 0; base < nq; base += DEPTH) {
+#pragma unroll
+            for (int dd = 0; dd < DEPTH; ++dd) {
+                if (base + dd < nq) {
+                    acc = Acc<R>::mma(o[dd].av[0], o[dd].xv[0], acc);
+                    acc = Acc<R>::mma(o[dd].av[1], o[dd].xv[1], acc);
+                    if (base + dd + DEPTH < nq) fetch(o[dd], q0 + base + dd + DEPTH);
+                }
+            }
+        }
+        // lanes of plane 0 hold (Q00, Q10), lanes of plane 1 (Q01, Q11), rows 2 lr and 2 lr + 1: Re Y = Q00 - Q11, Im Y = Q01 + Q10
+        d2v const qa = d2v{acc[0], acc[1]}, qb = xor8(d2v{acc[2], acc[3]});
+        d2v const yM = cp ? d2v{qa[0] + qb[0], qa[1] + qb[1]} : d2v{qa[0] - qb[0], qa[1] - qb[1]};   // this lane's plane of Y
+        d2v const yO = xor8(yM);
+        d2v const yr = cp ? yO : yM, yi = cp ? yM : yO;
+        if constexpr (UPD) {
+            d2v const uO = xor8(uM), ur = cp ? uO : uM, ui = cp ? uM : uO;
+            d2v nr, ni;
+            d2v w0, w1;     // the shadow vector: Re and Im of the two elements
+            if constexpr (HASH) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    int const row = 2 * lr + e;
+                    w0[e] = shadow_value(key, uint32_t(row * LN + j)); w1[e] = shadow_value(key, uint32_t(P + row * LN + j));
+                }
+            } else {
+                f2v const wO = f2v{__shfl_xor(wM[0], 8), __shfl_xor(wM[1], 8)};
+                w0 = cp ? d2v{wO[0], wO[1]} : d2v{wM[0], wM[1]}; w1 = cp ? d2v{wM[0], wM[1]} : d2v{wO[0], wO[1]};
+            }
+            if constexpr (EPI == EPI_XPAY_DOT) {          // v9 := A v6; v4 := v8 + beta v4; v4 := v9 + beta v4 (tfqmrgpu_core.hxx:196-202)
+                d2v const vO = xor8(vM), vr = cp ? vO : vM, vi = cp ? vM : vO;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    R const tr = __builtin_fma(-si, ui[e], __builtin_fma(sr, ur[e], vr[e]));
+                    R const ti = __builtin_fma(sr, ui[e], __builtin_fma(si, ur[e], vi[e]));
+                    nr[e] = __builtin_fma(-si, ti, __builtin_fma(sr, tr, yr[e]));
+                    ni[e] = __builtin_fma(sr, ti, __builtin_fma(si, tr, yi[e]));
+                }
+            } else {                                      // v8 := A v6; v5 := alfa v8 + v5 (tfqmrgpu_core.hxx:224-228)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    nr[e] = __builtin_fma(-si, yi[e], __builtin_fma(sr, yr[e], ur[e]));
+                    ni[e] = __builtin_fma(sr, yi[e], __builtin_fma(si, yr[e], ui[e]));
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {                 // every lane has both parts: the lanes of plane 0 are the ones that count
+                double const dr = nr[e], di = ni[e];
+                part[0] = __builtin_fma(-di, w1[e], __builtin_fma(dr, w0[e], part[0]));
+                part[1] = __builtin_fma(di, w0[e], __builtin_fma(dr, w1[e], part[1]));
+                if constexpr (EPI == EPI_AXPY_NRM_DOT) part[2] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[2]));
+            }
+            __builtin_nontemporal_store(yM, (d2v*)((R*)a.Y + yoff));
+            __builtin_nontemporal_store(cp ? ni : nr, (d2v*)((R*)a.e0 + yoff));
+        } else if constexpr (EPI == EPI_RESIDUAL) {       // |A x - b|^2, nothing stored (tfqmrgpu_core.hxx:265-269)
+            uint32_t const bq = a.bOfX[y];
+            d2v bM = d2v{0, 0};
+            if (bq != 0xffffffffu) bM = *(d2v const*)((R const*)a.B + size_t(bq) * 2 * P + mine);
+            d2v const bO = xor8(bM), br = cp ? bO : bM, bi = cp ? bM : bO;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                double const dr = yr[e] + R(-1) * br[e], di = yi[e] + R(-1) * bi[e];
+                part[0] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[0]));
+            }
+        } else {
+            __builtin_nontemporal_store(yM, (d2v*)((R*)a.Y + yoff));
+        }
+    }
+    if constexpr (NPL > 0) {
+        // the rows of a column sit 16 lanes apart (lr); lanes 0..7 (plane 0, lr 0) hold the column sums
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+            double v = part[p];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 8) s[wave][p][lane] = v;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < NPL * LN; e += 256) {
+            int const p = e / LN, jj = e % LN;
+            double const sum = ((s[0][p][jj] + s[1][p][jj]) + s[2][p][jj]) + s[3][p][jj];
+            write_record<EPI>(a, chunk, LN, p, jj, sum);
         }
     }
 }
@@ -962,8 +1110,18 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
     if (0 == nWG) return;
     if constexpr (LM == 16 && LN == 16 && sizeof(R) == 8) {
         if (a.ilv && a.chunkFirst) {   // the plan keeps its blocks row-pair-interleaved (tfq_plan.cpp: layoutBuffer); never the plain mode
-            if (a.hashV3 && EPI != EPI_RESIDUAL) k_spmm_ilv16<EPI, true><<<dim3(nWG), dim3(256), 0, s>>>(a);
-            else k_spmm_ilv16<EPI, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
+            constexpr bool canHashI = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
+            bool const hash = canHashI && a.hashV3;
+            if (a.aOnce) { if (hash) k_spmm_ilv16<EPI, canHashI, true><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16<EPI, false, true><<<dim3(nWG), dim3(256), 0, s>>>(a); }
+            else         { if (hash) k_spmm_ilv16<EPI, canHashI, false><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16<EPI, false, false><<<dim3(nWG), dim3(256), 0, s>>>(a); }
+            return;
+        }
+    }
+    if constexpr (LM == 8 && LN == 8 && sizeof(R) == 8) {
+        if (a.ilv && a.chunkFirst) {
+            constexpr bool canHash8 = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
+            if (canHash8 && a.hashV3) k_spmm_ilv8<EPI, canHash8><<<dim3(nWG), dim3(256), 0, s>>>(a);
+            else k_spmm_ilv8<EPI, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
             return;
         }
     }
@@ -1049,7 +1207,7 @@ static SpmmArgs spmm_args(int epi, DevPlan const& d) {
     a.chunkFirst = d.chunkFirst; a.chunkCol = d.chunkCol; a.CH = 0;
     a.order = d.order;
     a.ctl = d.ctl; a.v3 = d.v3; a.B = d.B; a.bOfX = d.bOfX; a.pz = d.pz; a.pd = d.pd;
-    a.hashV3 = d.hashV3; a.origCol = d.origCol; a.rowI = d.rowI; a.ilv = d.ilv;
+    a.hashV3 = d.hashV3; a.origCol = d.origCol; a.rowI = d.rowI; a.ilv = d.ilv; a.aOnce = d.aOnce;
     switch (epi) {
     case EPI_XPAY_DOT:     a.X = d.v6; a.Y = d.v9; a.e0 = d.v4; a.e1 = d.v8; a.sc = d.beta; a.gate = 1; break;
     case EPI_AXPY_NRM_DOT: a.X = d.v6; a.Y = d.v8; a.e0 = d.v5; a.sc = d.alfa; a.gate = 1; break;
