@@ -9,6 +9,12 @@
 //       solves the <LinearProblem> (schema of tfqmrgpu_example_xml_reader.hxx:125-292) through createPlan ->
 //       bufferSize -> setBuffer -> setMatrix -> solve -> getInfo -> getMatrix and compares with the stored X if any
 //       (:178-205).  Blocks of the XML are row-major; transposition flag 'n' (see DESIGN.md on the reference's 't').
+//       Extensions of this build, printed behind the reference's own result lines:
+//         multi:  the host re-computation is timed (threads over the Y blocks) = the CPU number beside the GPU one, and the
+//                 multiply is priced against the MI355X roofs (compulsory bytes of SURVEY 8d / HBM 8 TB/s, flops / matrix peak);
+//         tfQMR:  iterations per second, the fused multiply kernel of the iteration against the HBM roof (per-kernel times from
+//                 tfqmrgpuExt_getProfile), and `--gpus N` anywhere on the command line: N processes, one per GPU, the block
+//                 columns of X/B sharded with tfqmrgpuExt_shardColumns, the stopping test all-reduced by the library over RCCL.
 //   bench_tfqmrgpu read <problem.xml>
 //       parses the file with the reader below and prints what it found (no GPU call; used by tests/test_fd_generator.py).
 // The XML reader below handles exactly that schema (elements with attributes and whitespace-separated numbers);
@@ -25,7 +31,10 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <hip/hip_runtime_api.h>
 #include <zlib.h>
@@ -133,27 +142,40 @@ int bench_multi(int argc, char** argv) {
     std::vector<char> Yg(yBytes);
     CHECK_HIP(hipMemcpy(Yg.data(), dY, yBytes, hipMemcpyDeviceToHost));
     auto get = [&](std::vector<char> const& v, size_t idx) { return dbl ? ((double const*)v.data())[idx] : double(((float const*)v.data())[idx]); };
-    double maxdev = 0;
     size_t const PA = size_t(lm) * lm, PX = size_t(lm) * ln;
-    std::vector<double> yr(PX), yi(PX);
-    for (long y = 0; y < nY; ++y) {
-        std::fill(yr.begin(), yr.end(), 0.0); std::fill(yi.begin(), yi.end(), 0.0);
-        for (uint32_t q = starts[y]; q < starts[y + 1]; ++q) {
-            size_t const a0 = size_t(pairs[2 * q]) * 2 * PA, x0 = size_t(pairs[2 * q + 1]) * 2 * PX;
-            for (int k = 0; k < lm; ++k)
-                for (int i = 0; i < lm; ++i) {
-                    double const ar = get(A, a0 + k * lm + i), ai = get(A, a0 + PA + k * lm + i);   // A[k][i]: stored transposed
-                    for (int j = 0; j < ln; ++j) {
-                        double const xr = get(X, x0 + k * ln + j), xi = get(X, x0 + PX + k * ln + j);
-                        yr[i * ln + j] += ar * xr - ai * xi; yi[i * ln + j] += ar * xi + ai * xr;
-                    }
+    unsigned const nthreads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    std::vector<double> devs(nthreads, 0.0);
+    double const tc0 = now();
+    {   // the reference checks with an OpenMP loop over the Y blocks (bench_tfqmrgpu.cu:358-365); here plain threads
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nthreads; ++t) pool.emplace_back([&, t] {
+            std::vector<double> yr(PX), yi(PX);
+            double md = 0;
+            for (long y = t; y < nY; y += nthreads) {
+                std::fill(yr.begin(), yr.end(), 0.0); std::fill(yi.begin(), yi.end(), 0.0);
+                for (uint32_t q = starts[y]; q < starts[y + 1]; ++q) {
+                    size_t const a0 = size_t(pairs[2 * q]) * 2 * PA, x0 = size_t(pairs[2 * q + 1]) * 2 * PX;
+                    for (int k = 0; k < lm; ++k)
+                        for (int i = 0; i < lm; ++i) {
+                            double const ar = get(A, a0 + k * lm + i), ai = get(A, a0 + PA + k * lm + i);   // A[k][i]: stored transposed
+                            for (int j = 0; j < ln; ++j) {
+                                double const xr = get(X, x0 + k * ln + j), xi = get(X, x0 + PX + k * ln + j);
+                                yr[i * ln + j] += ar * xr - ai * xi; yi[i * ln + j] += ar * xi + ai * xr;
+                            }
+                        }
                 }
-        }
-        for (size_t e = 0; e < PX; ++e) {
-            maxdev = std::max(maxdev, std::abs(get(Yg, size_t(y) * 2 * PX + e) - yr[e]));
-            maxdev = std::max(maxdev, std::abs(get(Yg, size_t(y) * 2 * PX + PX + e) - yi[e]));
-        }
+                for (size_t e = 0; e < PX; ++e) {
+                    md = std::max(md, std::abs(get(Yg, size_t(y) * 2 * PX + e) - yr[e]));
+                    md = std::max(md, std::abs(get(Yg, size_t(y) * 2 * PX + PX + e) - yi[e]));
+                }
+            }
+            devs[t] = md;
+        });
+        for (auto& th : pool) th.join();
     }
+    double const tcpu = now() - tc0;
+    double maxdev = 0;
+    for (double d : devs) maxdev = std::max(maxdev, d);
     std::printf("# GPU maxdev %g\n", maxdev);
     int rc = 0;
     if (maxdev > 1e-4) { std::printf("# Warning! GPU result has large deviations (%g) for blockDim=%d x %d\n", maxdev, lm, ln); rc = 1; }
@@ -161,6 +183,18 @@ int bench_multi(int argc, char** argv) {
         char const ch = dbl ? 'F' : 'f';
         std::printf("# GPU performed %.3f T%clop in %.3f seconds\n", nflop * 1e-12, ch, tsum);
         std::printf("# GPU performance (lm,ln,tune)=(%3d,%3d,%d) is  %.1f G%clop/sec\n", lm, ln, 0, nflop * 1e-9 / tsum, ch);
+        // ---- not in the reference: the CPU beside it and the MI355X roofs (compulsory bytes = the A blocks that
+        // occur + X read once + Y written once + index lists; HBM3E 8 TB/s, matrix peaks 78.6 / 157.3 TFLOP/s)
+        double const flop1 = double(nPairs) * 8.0 * lm * lm * ln;
+        std::printf("# CPU performance (host re-computation in double, %u threads) is  %.2f GFlop/sec (%.3f seconds)\n", nthreads, flop1 * 1e-9 / tcpu, tcpu);
+        std::vector<char> usedA(size_t(nA), 0); size_t nAref = 0;
+        for (size_t q = 0; q < nPairs; ++q) if (!usedA[pairs[2 * q]]) { usedA[pairs[2 * q]] = 1; ++nAref; }
+        double const bytes = double(nAref) * 2 * PA * rb + double(nX + nY) * 2 * PX * rb + 4.0 * (nY + 1) + 8.0 * nPairs;
+        double const t1 = tsum / (double(nsamp) * nrep), peak = dbl ? 78.6e12 : 157.3e12;
+        bool const hbm = bytes / 8.0e12 >= flop1 / peak;
+        std::printf("# MI355X roofline: %.1f GB/s of compulsory bytes (%.3f of 8 TB/s HBM), %.2f T%clop/s (%.3f of the %.1f T%clop/s matrix peak): %s-bound, fraction %.3f\n",
+                    bytes * 1e-9 / t1, bytes / t1 / 8.0e12, flop1 * 1e-12 / t1, ch, flop1 / t1 / peak, peak * 1e-12, ch,
+                    hbm ? "HBM" : "matrix-pipe", hbm ? bytes / t1 / 8.0e12 : flop1 / t1 / peak);
     }
     CHECK_TFQ(tfqmrgpuDestroyHandle(handle));
     for (void* p : {dA, dX, dY, (void*)dS, (void*)dP}) (void)hipFree(p);
