@@ -31,6 +31,10 @@ def test_multi_mode_on_the_reference_plan_file(prec):
     tflop = float(re.search(r"# GPU performed (\S+) T", r.stdout).group(1))
     assert tflop == pytest.approx(6 * 50526 * 8.0 * 16 ** 3 * 1e-12, abs=6e-4)
     assert re.search(r"# GPU performance \(lm,ln,tune\)=\( 16, 16,0\) is +\S+ G[fF]lop/sec", r.stdout)
+    # this build's extension: the CPU re-computation timed beside it, and the roofline fraction
+    assert re.search(r"# CPU performance \(host re-computation in double, \d+ threads\) is +\S+ GFlop/sec", r.stdout)
+    m = re.search(r"# MI355X roofline: (\S+) GB/s of compulsory bytes \((\S+) of 8 TB/s HBM\), (\S+) T[fF]lop/s \((\S+) of the (\S+) T[fF]lop/s matrix peak\): (\S+)-bound, fraction (\S+)", r.stdout)
+    assert m and float(m.group(5)) == (157.3 if prec == "f" else 78.6) and 0 < float(m.group(7)) < 1
 
 
 @pytest.mark.gpu
@@ -43,3 +47,21 @@ def test_tfqmr_mode_matches_the_golden_solve():
     # the default (hash) shadow vector is not the golden run's glibc sequence: same system, nearly the same count
     assert abs(int(m.group(2)) - int(g["solve_z_iterations"])) <= 3
     assert float(m.group(1)) <= float(g["solve_z_threshold"])
+
+
+@pytest.mark.gpu
+def test_tfqmr_mode_extension_lines_and_one_rank_through_rccl():
+    # iterations per second and the fused multiply against the HBM roof; `--gpus 1`: a child process per GPU, RCCL communicator
+    g = np.load(os.path.join(GOLD, "fd_16x16_2d.npz"))
+    plain = subprocess.run([EXE, "tfQMR", os.path.join(GOLD, "fd_16x16_2d.xml"), "z", "1", "2000"], capture_output=True, text=True, timeout=300)
+    assert plain.returncode == 0, plain.stdout + plain.stderr
+    assert re.search(r"# GPU iterations per second: \S+ \(9 block columns x 16 right-hand sides", plain.stdout)
+    m = re.search(r"# MI355X roofline: fused multiply (spmm_v4_dot|spmm_v5_nrm_dot), (\d+) launches of (\S+) ms: (\S+) GB/s of algorithmic bytes = (\S+) of 8 TB/s HBM", plain.stdout)
+    assert m and int(m.group(2)) == int(g["solve_z_iterations"]) and 0 < float(m.group(5)) < 1
+    ranks = subprocess.run([EXE, "tfQMR", os.path.join(GOLD, "fd_16x16_2d.xml"), "z", "1", "2000", "--gpus", "1"],
+                           capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert ranks.returncode == 0, ranks.stdout + ranks.stderr
+    a = re.search(r"# GPU converged to (\S+) in (\d+) iterations", plain.stdout)
+    b = re.search(r"# GPU converged to (\S+) in (\d+) iterations", ranks.stdout)
+    assert a.groups() == b.groups()                                  # the all-reduced stopping test decides the same
+    assert re.search(r"# 1 GPUs: \S+ T[fF]lop in \S+ seconds \(slowest rank\) = \S+ T[fF]lop/s aggregate, %s iterations" % a.group(2), ranks.stdout)

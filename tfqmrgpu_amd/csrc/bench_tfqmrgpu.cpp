@@ -29,6 +29,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <set>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -322,27 +323,58 @@ int bench_read(int argc, char** argv) {
     return 0;
 }
 
-int bench_tfqmr(int argc, char** argv) {
-    std::string const path = (argc > 2) ? argv[2] : "problem";
-    char p0 = (argc > 3) ? char(argv[3][0] | 32) : 'z';
-    char const prec = ('d' == p0 || 'z' == p0) ? 'z' : 'c';
-    int const maxiter = (argc > 5) ? std::atoi(argv[5]) : 2000;
-    std::printf("\n# read file '%s' as input.\n", path.c_str());
+// one rank of the tfQMR mode: the whole problem (nranks == 1) or the block columns tfqmrgpuExt_shardColumns gives this rank
+int tfqmr_rank(std::string const& path, char prec, int maxiter, int rank, int nranks, std::string const& tmp) {
+    bool const root = (0 == rank);
+    if (root) std::printf("\n# read file '%s' as input.\n", path.c_str());
     ProblemFile pf;
     if (!read_problem(path, pf)) return 1;
     double const tol = pf.tol;
-    Operator const &A = pf.A, &B = pf.B, &X = pf.X;
+    Operator const &A = pf.A; Operator B = pf.B, X = pf.X;
     int const mb = int(A.rowPtr.size()) - 1, LM = A.rows, LN = B.cols;
-    std::printf("# requested precision= '%c' for LM= %d, LN= %d\n", prec, LM, LN);
-    std::printf("\n# nnzb for A=%zu, X=%zu, B=%zu\n", A.colInd.size(), X.colInd.size(), B.colInd.size());
-
+    if (nranks > 1) {   // this rank's block columns: sub-patterns of X and B, the values of its B blocks
+        tfqmrgpuShard_t sh;
+        CHECK_TFQ(tfqmrgpuExt_shardColumns(mb, X.rowPtr.data(), int(X.colInd.size()), X.colInd.data(), B.rowPtr.data(), int(B.colInd.size()),
+                                           B.colInd.data(), 0, nranks, rank, &sh));
+        Operator Bs, Xs;
+        Xs.rowPtr.assign(sh.rowPtrX, sh.rowPtrX + mb + 1); Xs.colInd.assign(sh.colIndX, sh.colIndX + sh.nnzbX); Xs.rows = X.rows; Xs.cols = X.cols;
+        Bs.rowPtr.assign(sh.rowPtrB, sh.rowPtrB + mb + 1); Bs.colInd.assign(sh.colIndB, sh.colIndB + sh.nnzbB); Bs.rows = B.rows; Bs.cols = B.cols;
+        size_t const blk = size_t(B.rows) * B.cols;
+        Bs.val.resize(size_t(sh.nnzbB) * blk);
+        for (int b = 0; b < sh.nnzbB; ++b) std::copy(B.val.begin() + size_t(sh.bBlocks[b]) * blk, B.val.begin() + size_t(sh.bBlocks[b] + 1) * blk, Bs.val.begin() + size_t(b) * blk);
+        std::printf("# [rank %d of %d] block columns %d .. %d: %d X blocks, %d B blocks\n", rank, nranks, sh.firstCol, sh.firstCol + sh.nCols - 1, sh.nnzbX, sh.nnzbB);
+        tfqmrgpuExt_freeShard(&sh);
+        B = std::move(Bs); X = std::move(Xs);
+        CHECK_HIP(hipSetDevice(rank));
+    }
+    if (root) {
+        std::printf("# requested precision= '%c' for LM= %d, LN= %d\n", prec, LM, LN);
+        std::printf("\n# nnzb for A=%zu, X=%zu, B=%zu\n", A.colInd.size(), X.colInd.size(), B.colInd.size());
+    }
     tfqmrgpuHandle_t handle = nullptr; tfqmrgpuBsrsvPlan_t plan = nullptr;
     CHECK_TFQ(tfqmrgpuCreateHandle(&handle));
+    if (nranks > 1 || !tmp.empty()) {   // RCCL communicator of the stopping test: rank 0 makes the id, the others read it from a file
+        char id[128];
+        std::string const idfile = tmp + "/rccl_id";
+        if (root) {
+            CHECK_TFQ(tfqmrgpuExt_commUniqueId(id));
+            std::ofstream(idfile + ".part", std::ios::binary).write(id, 128);
+            std::rename((idfile + ".part").c_str(), idfile.c_str());
+        } else {
+            for (int tries = 0; ; ++tries) {
+                std::ifstream f(idfile, std::ios::binary);
+                if (f && f.read(id, 128)) break;
+                if (tries > 6000) { std::fprintf(stderr, "[rank %d] no RCCL id after 60 s\n", rank); return 4; }
+                usleep(10000);
+            }
+        }
+        CHECK_TFQ(tfqmrgpuExt_commInit(handle, nranks, rank, id));
+    }
     CHECK_TFQ(tfqmrgpu_bsrsv_createPlan(handle, &plan, mb, A.rowPtr.data(), int(A.colInd.size()), A.colInd.data(),
         X.rowPtr.data(), int(X.colInd.size()), X.colInd.data(), B.rowPtr.data(), int(B.colInd.size()), B.colInd.data(), 0, 0));
     size_t nbytes = 0;
     CHECK_TFQ(tfqmrgpu_bsrsv_bufferSize(handle, plan, LM, LM, LN, LN, prec, &nbytes));
-    std::printf("# use %.6f GByte GPU memory\n", nbytes * 1e-9);
+    if (root) std::printf("# use %.6f GByte GPU memory\n", nbytes * 1e-9);
     void* buffer = nullptr;
     CHECK_TFQ(tfqmrgpuCreateWorkspace(&buffer, nbytes, 'd'));
     CHECK_TFQ(tfqmrgpu_bsrsv_setBuffer(handle, plan, buffer));
@@ -357,18 +389,19 @@ int bench_tfqmr(int argc, char** argv) {
     auto const Ah = convert(A.val), Bh = convert(B.val);
     CHECK_TFQ(tfqmrgpu_bsrsv_setMatrix(handle, plan, 'A', Ah.data(), prec, LM, LM, 'n', TFQMRGPU_LAYOUT_RIRIRIRI));
     CHECK_TFQ(tfqmrgpu_bsrsv_setMatrix(handle, plan, 'B', Bh.data(), prec, LN, LM, 'n', TFQMRGPU_LAYOUT_RIRIRIRI));
+    CHECK_TFQ(tfqmrgpuExt_setProfiling(plan, 1));
     CHECK_HIP(hipDeviceSynchronize());
     double const t0 = now();
     tfqmrgpuStatus_t const st = tfqmrgpu_bsrsv_solve(handle, plan, tol, maxiter);
     CHECK_HIP(hipDeviceSynchronize());
     double const dt = now() - t0;
-    tfqmrgpuPrintError(st);
+    if (root) tfqmrgpuPrintError(st);
     std::vector<char> Xh(X.colInd.size() * size_t(LM) * LN * 2 * (prec == 'z' ? 8 : 4));
     CHECK_TFQ(tfqmrgpu_bsrsv_getMatrix(handle, plan, 'X', Xh.data(), prec, LN, LM, 'n', TFQMRGPU_LAYOUT_RIRIRIRI));
     double residual = 0, flops = 0, flops_all = 0; int32_t iterations = 0;
     CHECK_TFQ(tfqmrgpu_bsrsv_getInfo(handle, plan, &residual, &iterations, &flops, &flops_all));
     int rc = int(st);
-    if (X.hasData) {
+    if (X.hasData && 1 == nranks) {
         double maxdev = 0, sum = 0, maxref = 0;
         for (size_t e = 0; e < X.val.size(); ++e) {
             double const xr = prec == 'z' ? ((double*)Xh.data())[2 * e] : ((float*)Xh.data())[2 * e];
@@ -381,13 +414,81 @@ int bench_tfqmr(int argc, char** argv) {
             if (maxdev >= 1e-5) rc = 1;
         }
     }
-    std::printf("# GPU converged to %.1e in %d iterations\n", residual, int(iterations));
     char const ch = (prec == 'z') ? 'F' : 'f';
-    std::printf("# GPU performed %.3f T%clop in %.3f seconds = %.3f T%clop/s\n", flops * 1e-12, ch, dt, flops * 1e-12 / std::max(dt, 1e-6), ch);
+    if (root) {
+        std::printf("# GPU converged to %.1e in %d iterations\n", residual, int(iterations));
+        std::printf("# GPU performed %.3f T%clop in %.3f seconds = %.3f T%clop/s\n", flops * 1e-12, ch, dt, flops * 1e-12 / std::max(dt, 1e-6), ch);
+        // ---- not in the reference: iterations per second and the fused multiply of the iteration against the HBM roof ----
+        std::printf("# GPU iterations per second: %.1f (%d block columns x %d right-hand sides each on this rank)\n", iterations / std::max(dt, 1e-9),
+                    int(std::set<int32_t>(X.colInd.begin(), X.colInd.end()).size()), LN);
+        int64_t launches[TFQMRGPU_PROFILE_CLASSES]; double ms[TFQMRGPU_PROFILE_CLASSES];
+        CHECK_TFQ(tfqmrgpuExt_getProfile(plan, launches, ms));
+        tfqmrgpuPlanView_t v;
+        CHECK_TFQ(tfqmrgpuExt_planView(plan, &v));
+        int const k = (ms[TFQMRGPU_PROF_SPMM_V4_DOT] >= ms[TFQMRGPU_PROF_SPMM_V5_NRM_DOT]) ? TFQMRGPU_PROF_SPMM_V4_DOT : TFQMRGPU_PROF_SPMM_V5_NRM_DOT;
+        if (launches[k] > 0) {
+            double const rb = (prec == 'z') ? 8 : 4, S = double(v.nnzbX) * 2 * LM * LN * rb, S3 = double(v.nnzbX) * 2 * LM * LN * 4;
+            std::vector<char> usedA(v.nnzbA, 0); double nAref = 0;
+            for (uint64_t q = 0; q < v.nPairs; ++q) if (!usedA[v.pairs[2 * q]]) { usedA[v.pairs[2 * q]] = 1; nAref += 1; }
+            double const bytes = ((TFQMRGPU_PROF_SPMM_V4_DOT == k) ? 5 : 4) * S + S3 + nAref * 2 * LM * LM * rb + 4.0 * (v.nnzbX + 1) + 8.0 * double(v.nPairs);
+            double const t1 = ms[k] * 1e-3 / double(launches[k]);
+            std::printf("# MI355X roofline: fused multiply %s, %lld launches of %.4f ms: %.1f GB/s of algorithmic bytes = %.3f of 8 TB/s HBM (%.2f T%clop/s)\n",
+                        (TFQMRGPU_PROF_SPMM_V4_DOT == k) ? "spmm_v4_dot" : "spmm_v5_nrm_dot", (long long)launches[k], t1 * 1e3, bytes * 1e-9 / t1,
+                        bytes / t1 / 8.0e12, double(v.nPairs) * 8.0 * LM * LM * LN * 1e-12 / t1, ch);
+        }
+    }
+    if (!tmp.empty()) {   // for the parent's aggregate line
+        std::ofstream f(tmp + "/rank" + std::to_string(rank));
+        f << flops << " " << dt << " " << iterations << " " << int(st) << "\n";
+    }
+    if (nranks > 1 || !tmp.empty()) CHECK_TFQ(tfqmrgpuExt_commDestroy(handle));
     CHECK_TFQ(tfqmrgpu_bsrsv_destroyPlan(handle, plan));
     CHECK_TFQ(tfqmrgpuDestroyWorkspace(buffer));
     CHECK_TFQ(tfqmrgpuDestroyHandle(handle));
     return rc;
+}
+
+int bench_tfqmr(int argc, char** argv) {
+    // `--gpus N` may stand anywhere; the positional arguments are the reference's
+    int gpus = 0;
+    std::vector<char*> pos;
+    for (int i = 0; i < argc; ++i) {
+        if (0 == std::strcmp(argv[i], "--gpus") && i + 1 < argc) { gpus = std::atoi(argv[++i]); continue; }
+        pos.push_back(argv[i]);
+    }
+    int const n = int(pos.size());
+    std::string const path = (n > 2) ? pos[2] : "problem";
+    char p0 = (n > 3) ? char(pos[3][0] | 32) : 'z';
+    char const prec = ('d' == p0 || 'z' == p0) ? 'z' : 'c';
+    int const maxiter = (n > 5) ? std::atoi(pos[5]) : 2000;
+    if (gpus < 1) return tfqmr_rank(path, prec, maxiter, 0, 1, "");
+    // one child process per GPU, started before this process has made any HIP call
+    char tmpl[] = "/tmp/bench_tfqmrgpu.XXXXXX";
+    char const* dir = mkdtemp(tmpl);
+    if (!dir) { std::perror("mkdtemp"); return 1; }
+    std::string const tmp = dir;
+    std::vector<pid_t> kids;
+    for (int r = 0; r < gpus; ++r) {
+        std::fflush(nullptr);
+        pid_t const pid = fork();
+        if (pid < 0) { std::perror("fork"); return 1; }
+        if (0 == pid) { int const rc = tfqmr_rank(path, prec, maxiter, r, gpus, tmp); std::fflush(nullptr); _exit(rc); }
+        kids.push_back(pid);
+    }
+    int worst = 0;
+    for (auto pid : kids) { int status = 0; waitpid(pid, &status, 0); worst = std::max(worst, WIFEXITED(status) ? WEXITSTATUS(status) : 128); }
+    double flops = 0, tmax = 0; int its = 0;
+    for (int r = 0; r < gpus; ++r) {
+        std::ifstream f(tmp + "/rank" + std::to_string(r));
+        double fl = 0, dt = 0; int it = 0, st = 0;
+        if (f >> fl >> dt >> it >> st) { flops += fl; tmax = std::max(tmax, dt); its = it; }
+        std::remove((tmp + "/rank" + std::to_string(r)).c_str());
+    }
+    std::remove((tmp + "/rccl_id").c_str()); rmdir(tmp.c_str());
+    char const ch = (prec == 'z') ? 'F' : 'f';
+    std::printf("# %d GPUs: %.3f T%clop in %.3f seconds (slowest rank) = %.3f T%clop/s aggregate, %d iterations, %.1f iterations per second\n",
+                gpus, flops * 1e-12, ch, tmax, flops * 1e-12 / std::max(tmax, 1e-9), ch, its, its / std::max(tmax, 1e-9));
+    return worst;
 }
 
 } // namespace
