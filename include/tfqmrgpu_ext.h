@@ -79,7 +79,12 @@ tfqmrgpuStatus_t tfqmrgpuExt_getShadowVector(tfqmrgpuHandle_t handle, tfqmrgpuBs
 /* Y[iY] = sum over pairs p in [starts[iY], starts[iY+1]) of A[pairs[2p]] * X[pairs[2p+1]]
  * All pointers are DEVICE pointers.  Blocks are in the native layout RRRRIIII:
  * A[nnzbA][2][lm(k)][lm(i)] (transposed), X|Y[nnzb][2][lm][ln].
- * Same contract as the reference kernel gemmNxNf (tfqmrgpu_blockmult.hxx:9-93). */
+ * Same contract as the reference kernel gemmNxNf (tfqmrgpu_blockmult.hxx:9-93).
+ * Accuracy note: for complex<double> blocks larger than 16 x 16 the kernels form a complex product from THREE real
+ * products (P1 = Re A Re X, P2 = Im A Im X, P3 = (Re A + Im A)(Re X + Im X); Re = P1 - P2, Im = P3 - P1 - P2): the error of
+ * both components is bounded relative to |A| |X| (k eps |A||X| for k accumulated terms), not relative to the component itself --
+ * an imaginary part that is 10^-k times smaller than the real part keeps k digits fewer than with four products.
+ * TFQMRGPU_3M=0 in the environment selects four products everywhere (tests/test_gpu_parity.py::test_three_product_form_error_bound). */
 tfqmrgpuStatus_t tfqmrgpuExt_multiply(tfqmrgpuHandle_t handle,
     char precision, int lm, int ln,
     uint32_t nnzbY, uint32_t const *starts_d, uint32_t const *pairs_d,

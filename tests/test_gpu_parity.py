@@ -530,3 +530,31 @@ def test_apply_operator_on_plan_data(oracle, prec, shape):
         assert np.array_equal(s.get_matrix(), got)
     eps = 1e-13 if prec == "z" else 3e-5
     assert np.abs(got - want).max() <= eps * LM * 6 * max(1.0, np.abs(want).max())
+
+
+def test_three_product_form_error_bound(torch_cuda, oracle):
+    """32 x 32 complex<double> uses three real products per complex one (TFQMRGPU_3M): with imaginary
+    parts 1e-8 times smaller than the real parts the result is accurate relative to |A||X| (a few eps per accumulated term),
+    i.e. the imaginary part loses about 8 digits against the oracle's four-product sum -- the documented bound, not more"""
+    torch = torch_cuda
+    LM = LN = 32
+    rng = np.random.default_rng(77)
+    nY, nA, nX = 12, 9, 11
+    starts, pairs = _rand_pairs(rng, nY, nA, nX, 6)
+    A = rng.uniform(-1, 1, (nA, 2, LM, LM)); A[:, 1] *= 1e-8
+    X = rng.uniform(-1, 1, (nX, 2, LM, LN)); X[:, 1] *= 1e-8
+    Xp = np.concatenate([X, np.zeros((max(0, nY - nX), 2, LM, LN))])
+    want = oracle.spmm("z", LM, LN, starts, pairs, A, Xp)[:nY]
+    dA, dX = torch.from_numpy(A).cuda(), torch.from_numpy(X).cuda()
+    dS, dP = torch.from_numpy(starts.view(np.int32)).cuda(), torch.from_numpy(pairs.view(np.int32)).cuda()
+    dY = torch.zeros((nY, 2, LM, LN), dtype=torch.float64, device="cuda")
+    with T.Solver() as s:
+        assert T.lib.tfqmrgpuExt_multiply(s.handle, b"z", LM, LN, nY, dS.data_ptr(), dP.data_ptr(), dA.data_ptr(), dX.data_ptr(), dY.data_ptr()) == 0
+        torch.cuda.synchronize()
+    got = dY.cpu().numpy()
+    scale = 6 * LM * 1.0                                  # |A||X| summed over at most 6 products of 32 terms, entries <= 1
+    eps = np.finfo(np.float64).eps
+    assert np.abs(got[:, 0] - want[:, 0]).max() <= 8 * eps * scale
+    assert np.abs(got[:, 1] - want[:, 1]).max() <= 8 * eps * scale      # absolute: the same bound as the real part ...
+    rel_im = np.abs(got[:, 1] - want[:, 1]).max() / np.abs(want[:, 1]).max()
+    assert rel_im <= 8 * eps * scale / 1e-8                               # ... i.e. up to 1e8 times eps relative to Im itself
