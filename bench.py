@@ -287,6 +287,7 @@ def main():
             tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tp):   # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc cannot run inside this timing run)
                 rl["traffic"] = json.load(open(tp)).get(args.workload, {}).get(dom)
+            if rl["traffic"] is not None:
                 rl["traffic_source"] = "profiles/pmc_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE of scripts/pmc_collect.sh, kept from the latest PMC run; not measured in this run)"
 
             # The BSR multiply Y = A*X on its own, twice:

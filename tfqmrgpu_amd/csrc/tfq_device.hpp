@@ -36,7 +36,7 @@ struct DevPlan {
     bool dbl;
     uint32_t nCols, nnzbX, nnzbB, nnzbA, nChunks;
     int hashV3;                                // v3 holds the counter-based hash below: kernels may recompute instead of reading it
-    int ilv;                                   // element order inside a block plane: 0 native [r][s], 1 row pairs interleaved (see ilv_offset)
+    int ilv;                                   // element order inside a block plane: 0 native [r][s], G = 2 | 4: groups of G rows interleaved (see ilv_offset)
     int aOnce;                                 // a multiply uses every A block about once (<= 1.5 times): A is streamed, not cached
     void *x, *v4, *v5, *v6, *v7, *v8, *v9, *B, *A;
     float* v3;
@@ -77,13 +77,14 @@ __host__ __device__ inline float shadow_value(uint64_t key, uint32_t e) {
 
 // ---- element order inside one plane (Re or Im) of a block -------------------------------------------------------------
 // native (the reference's, tfqmrgpu_linalg.hxx:332-345):   [r][s]            r = row (k for the transposed A blocks), s contiguous
-// row pairs interleaved (16 x 16 complex<double> plans):    [r/2][s][r%2]     two consecutive rows of one column are 16 contiguous bytes
+// groups of G rows interleaved:                             [r/G][s][r%G]     G consecutive rows of one column are 16 contiguous bytes:
+//                                                           G = 2 for complex<double> (16 x 16, 8 x 8), G = 4 for complex<float> (16 x 16)
 // The second form exists for the multiply: a lane of the 16x16x4 MFMA then fetches the operands of two k-steps, and the
 // two rows of a column that its accumulator registers hold, as ONE 16-byte access -- half the memory instructions for the
 // operands, the epilogue vectors and the stores (measured on P2: fused multiplies 0.684 -> 0.628 ms, profiles/r02_lab.txt).
 // Everything else (vector updates, reductions) is elementwise and only needs to know which column an element belongs to.
-__host__ __device__ inline int ilv_offset(int r, int s, int nC) { return ((r >> 1) * nC + s) * 2 + (r & 1); }
-__host__ __device__ inline int plane_offset(int ilv, int r, int s, int nC) { return ilv ? ilv_offset(r, s, nC) : r * nC + s; }
+__host__ __device__ inline int ilv_offset(int G, int r, int s, int nC) { return ((r / G) * nC + s) * G + (r % G); }
+__host__ __device__ inline int plane_offset(int ilv, int r, int s, int nC) { return ilv ? ilv_offset(ilv, r, s, nC) : r * nC + s; }
 
 enum { EPI_NONE = 0, EPI_XPAY_DOT = 1, EPI_AXPY_NRM_DOT = 2, EPI_RESIDUAL = 3 };
 

@@ -235,10 +235,13 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     p.realBytes = ('z' == precision) ? 8 : 4;
     size_t const blockElems = size_t(2) * LM * LN;
     p.S = size_t(p.nnzbX) * blockElems * p.realBytes;
-    // row-pair-interleaved element order where the multiply kernel is written for it: 16 x 16 and 8 x 8 complex<double>
-    // (TFQMRGPU_ILV=0 keeps the native order everywhere, for A/B runs)
+    // groups of rows interleaved (16-byte accesses for one column) where a multiply kernel is written for it: 16 x 16 and 8 x 8
+    // complex<double> (pairs), 16 x 16 complex<float> (quads).  TFQMRGPU_ILV=0 keeps the native order everywhere (A/B runs),
+    // =16: only 16 x 16 z, =2: only the double shapes
     static int const ilvEnv = [] { auto v = std::getenv("TFQMRGPU_ILV"); return v ? std::atoi(v) : 1; }();
-    p.ilv = (ilvEnv && ((16 == LM && 16 == LN) || (8 == LM && 8 == LN && ilvEnv != 16)) && 'z' == precision) ? 1 : 0;   // TFQMRGPU_ILV=16: only 16 x 16
+    p.ilv = 0;
+    if (ilvEnv && 'z' == precision && ((16 == LM && 16 == LN) || (8 == LM && 8 == LN && ilvEnv != 16))) p.ilv = 2;
+    if (1 == ilvEnv && 'c' == precision && 16 == LM && 16 == LN) p.ilv = 4;
 
     // chunks: runs of CH blocks inside one column, sized so that a chunk of one vector is 8..16 KiB and the
     // grid has a few thousand work groups when the problem is large enough

@@ -737,6 +737,132 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 16 x 16 complex<float> with groups of FOUR rows interleaved (plane[r/4][s][r%4]): the float counterpart of k_spmm_ilv16.
+// A lane of v_mfma_f32_16x16x4_f32 loads the k quad lr = lane / 16 (k = 4 lr .. 4 lr + 3) of its column as ONE 16-byte access --
+// MFMA step e contracts k = 4 lr + e -- and its four accumulator registers are the rows 4 lr .. 4 lr + 3 of column lane % 16
+// (the C layout of the f32 instruction), i.e. again one 16-byte piece of every epilogue vector: a block product takes 4 wave-wide
+// loads of 1 KiB (16 of 256 bytes in k_spmm_mfma<float, 16, 16>), an epilogue 2 accesses per vector.  16 x 16 in float is the
+// default shape of the reference's own benchmark (`bench_tfqmrgpu multi`, bench_tfqmrgpu.cu:445-450).
+using f4v = __attribute__((ext_vector_type(4))) float;
+
+template <int EPI, bool HASH, bool ANT = false>
+__global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
+    if (gate_closed(a)) return;
+    using R = float;
+    constexpr int LN = 16, P = 256, NPL = EpiPlanes<EPI>::N;
+    constexpr bool UPD = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
+    int const lane = threadIdx.x & 63;
+    int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int const lr = lane >> 4, lc = lane & 15;
+    using CU32 = __attribute__((address_space(4))) uint32_t const*;
+    CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
+    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    uint32_t const first = a.chunkFirst[chunk], last = a.chunkFirst[chunk + 1], col = a.chunkCol[chunk];
+    R sr = 0, si = 0;
+    if constexpr (UPD) { sr = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + lc]; si = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + lc]; }
+    double part[NPL > 0 ? NPL : 1] = {};
+    __shared__ double s[4][NPL > 0 ? NPL : 1][LN];
+
+    int const mine = (lr * 16 + lc) * 4;                       // this lane's 16 bytes of a plane: quad lr, column (or A row) lc
+    struct Ops { f4v ar, ai, xr, xi; };
+    R const* const A0 = (R const*)a.A + mine;
+    R const* const X0 = (R const*)a.X + mine;
+    auto fetch = [&](Ops& o, uint32_t q) __attribute__((always_inline)) {
+        R const* Ab = A0 + size_t(pairs[2 * size_t(q)]) * 2 * P;
+        R const* Xb = X0 + size_t(pairs[2 * size_t(q) + 1]) * 2 * P;
+        if constexpr (ANT) { o.ar = __builtin_nontemporal_load((f4v const*)Ab); o.ai = __builtin_nontemporal_load((f4v const*)(Ab + P)); }
+        else { o.ar = *(f4v const*)Ab; o.ai = *(f4v const*)(Ab + P); }
+        o.xr = *(f4v const*)Xb; o.xi = *(f4v const*)(Xb + P);
+    };
+    for (uint32_t u = wave; u < last - first; u += 4) {
+        uint32_t const y = first + u;
+        uint64_t const key = HASH ? shadow_key(uint32_t(a.origCol[col]), a.rowI[y]) : 0;
+        f4 cre = f4{0, 0, 0, 0}, cim = f4{0, 0, 0, 0};
+        auto mma = [&](Ops const& o) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                R const nai = -o.ai[e];
+                cre = Acc<R>::mma(o.ar[e], o.xr[e], cre);
+                cim = Acc<R>::mma(o.ar[e], o.xi[e], cim);
+                cre = Acc<R>::mma(nai, o.xi[e], cre);
+                cim = Acc<R>::mma(o.ai[e], o.xr[e], cim);
+            }
+        };
+        uint32_t const q0 = starts[y], q1 = starts[y + 1];
+        Ops o0, o1;
+        if (q0 < q1) fetch(o0, q0);
+        if (q0 + 1 < q1) fetch(o1, q0 + 1);
+        size_t const yoff = size_t(y) * 2 * P + mine;          // rows 4 lr .. 4 lr + 3 of column lc
+        f4v ur, ui, vr, vi, wr, wi;
+        if constexpr (UPD) {
+            ur = __builtin_nontemporal_load((f4v const*)((R const*)a.e0 + yoff)); ui = __builtin_nontemporal_load((f4v const*)((R const*)a.e0 + yoff + P));
+            if constexpr (EPI == EPI_XPAY_DOT) { vr = __builtin_nontemporal_load((f4v const*)((R const*)a.e1 + yoff)); vi = __builtin_nontemporal_load((f4v const*)((R const*)a.e1 + yoff + P)); }
+            if constexpr (!HASH) { wr = __builtin_nontemporal_load((f4v const*)(a.v3 + yoff)); wi = __builtin_nontemporal_load((f4v const*)(a.v3 + yoff + P)); }
+        }
+        uint32_t q = q0;
+        for (; q + 2 <= q1; q += 2) {
+            mma(o0);
+            if (q + 2 < q1) fetch(o0, q + 2);
+            mma(o1);
+            if (q + 3 < q1) fetch(o1, q + 3);
+        }
+        if (q < q1) mma(o0);
+
+        f4v yr, yi, nr, ni;
+        f4v br = f4v{0, 0, 0, 0}, bi = f4v{0, 0, 0, 0};
+        if constexpr (EPI == EPI_RESIDUAL) {
+            uint32_t const bq = a.bOfX[y];
+            if (bq != 0xffffffffu) { R const* b = (R const*)a.B + size_t(bq) * 2 * P + mine; br = *(f4v const*)b; bi = *(f4v const*)(b + P); }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            yr[e] = cre[e]; yi[e] = cim[e];
+            // explicit fused multiply-adds: the HASH and the v3-reading instance must round alike (tests compare them bit by bit)
+            if constexpr (EPI == EPI_XPAY_DOT) {         // v9 := A v6; v4 := v8 + beta v4; v4 := v9 + beta v4 (tfqmrgpu_core.hxx:196-202)
+                R const tr = __builtin_fmaf(-si, ui[e], __builtin_fmaf(sr, ur[e], vr[e]));
+                R const ti = __builtin_fmaf(sr, ui[e], __builtin_fmaf(si, ur[e], vi[e]));
+                nr[e] = __builtin_fmaf(-si, ti, __builtin_fmaf(sr, tr, yr[e]));
+                ni[e] = __builtin_fmaf(sr, ti, __builtin_fmaf(si, tr, yi[e]));
+            } else if constexpr (EPI == EPI_AXPY_NRM_DOT) { // v8 := A v6; v5 := alfa v8 + v5 (tfqmrgpu_core.hxx:224-228)
+                nr[e] = __builtin_fmaf(-si, yi[e], __builtin_fmaf(sr, yr[e], ur[e]));
+                ni[e] = __builtin_fmaf(sr, yi[e], __builtin_fmaf(si, yr[e], ui[e]));
+            }
+            if constexpr (UPD) {
+                int const row = 4 * lr + e;
+                double w0, w1;
+                if constexpr (HASH) { w0 = shadow_value(key, uint32_t(row * LN + lc)); w1 = shadow_value(key, uint32_t(P + row * LN + lc)); }
+                else { w0 = wr[e]; w1 = wi[e]; }
+                double const dr = nr[e], di = ni[e];
+                part[0] = __builtin_fma(-di, w1, __builtin_fma(dr, w0, part[0]));
+                part[1] = __builtin_fma(di, w0, __builtin_fma(dr, w1, part[1]));
+                if constexpr (EPI == EPI_AXPY_NRM_DOT) part[2] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[2]));
+            } else if constexpr (EPI == EPI_RESIDUAL) {     // |A x - b|^2, nothing stored (tfqmrgpu_core.hxx:265-269)
+                R const rr = yr[e] + R(-1) * br[e], ri = yi[e] + R(-1) * bi[e];
+                double const dr = rr, di = ri;
+                part[0] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[0]));
+            }
+        }
+        if constexpr (EPI != EPI_RESIDUAL) { __builtin_nontemporal_store(yr, (f4v*)((R*)a.Y + yoff)); __builtin_nontemporal_store(yi, (f4v*)((R*)a.Y + yoff + P)); }
+        if constexpr (UPD) { __builtin_nontemporal_store(nr, (f4v*)((R*)a.e0 + yoff)); __builtin_nontemporal_store(ni, (f4v*)((R*)a.e0 + yoff + P)); }
+    }
+    if constexpr (NPL > 0) {
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+            double v = part[p];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (lane < 16) s[wave][p][lane] = v;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < NPL * LN; e += 256) {
+            int const p = e / LN, j = e % LN;
+            double const sum = ((s[0][p][j] + s[1][p][j]) + s[2][p][j]) + s[3][p][j];
+            write_record<EPI>(a, chunk, LN, p, j, sum);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 8 x 8 complex<double> on the row-pair-interleaved element order (BASELINE config 5: the bandwidth-bound shape).
 // A block is 1 KiB = ONE wave-wide 16-byte access: lane (lr = lane / 16, c = (lane % 16) / 8, j = lane % 8) holds the k pair lr
 // (k = 2 lr, 2 lr + 1) of plane c (Re | Im) and column j.  The matrix tile is filled like in k_spmm_mfma8:
@@ -1118,6 +1244,15 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
             bool const hash = canHashI && a.hashV3;
             if (a.aOnce) { if (hash) k_spmm_ilv16<EPI, canHashI, true><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16<EPI, false, true><<<dim3(nWG), dim3(256), 0, s>>>(a); }
             else         { if (hash) k_spmm_ilv16<EPI, canHashI, false><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16<EPI, false, false><<<dim3(nWG), dim3(256), 0, s>>>(a); }
+            return;
+        }
+    }
+    if constexpr (LM == 16 && LN == 16 && sizeof(R) == 4) {
+        if (4 == a.ilv && a.chunkFirst) {   // quads of rows interleaved
+            constexpr bool canHashF = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
+            bool const hash = canHashF && a.hashV3;
+            if (a.aOnce) { if (hash) k_spmm_ilv16f<EPI, canHashF, true><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16f<EPI, false, true><<<dim3(nWG), dim3(256), 0, s>>>(a); }
+            else         { if (hash) k_spmm_ilv16f<EPI, canHashF, false><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16f<EPI, false, false><<<dim3(nWG), dim3(256), 0, s>>>(a); }
             return;
         }
     }

@@ -67,11 +67,11 @@ template <int N> __device__ inline void ldf(float (&r)[N], float const* p) {
 template <typename R, int LN, int VEC>
 struct Scal {
     R re[VEC], im[VEC];
-    // ilv: the elements of an item are consecutive ROWS of one column (tfq_device.hpp: ilv_offset), else consecutive columns
+    // ilv = G > 0: every G consecutive elements are rows of ONE column (tfq_device.hpp: ilv_offset), else consecutive columns
     __device__ inline void load(R const* a, uint32_t col, int t, int ilv = 0) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            int const j = ilv ? ((t * VEC + v) >> 1) % LN : (t * VEC + v) % LN;
+            int const j = ilv ? ((t * VEC + v) / ilv) % LN : (t * VEC + v) % LN;
             re[v] = a[(size_t(col) * 2 + 0) * LN + j];
             im[v] = a[(size_t(col) * 2 + 1) * LN + j];
         }
@@ -107,8 +107,9 @@ __device__ inline void chunk_reduce(double (&acc)[NPL][VEC], double* s, double* 
     for (int e = t; e < NPL * LN; e += 256) {
         int const p = e / LN, j = e % LN;
         double sum = 0;
-        if (ilv) {   // element m of the work group's slice belongs to column (m / 2) % LN: pairs of rows, then the next column
-            for (int n = 0; n < terms / 2; ++n) sum += s[p * (256 * VEC) + (n * LN + j) * 2] + s[p * (256 * VEC) + (n * LN + j) * 2 + 1];
+        if (ilv) {   // element m of the work group's slice belongs to column (m / G) % LN: G rows, then the next column
+            for (int n = 0; n < terms / ilv; ++n)
+                for (int g = 0; g < ilv; ++g) sum += s[p * (256 * VEC) + (n * LN + j) * ilv + g];
         } else
         for (int n = 0; n < terms; ++n) sum += s[p * (256 * VEC) + n * LN + j];
         out[p * LN + j] = sum;
