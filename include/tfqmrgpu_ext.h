@@ -75,6 +75,15 @@ tfqmrgpuStatus_t tfqmrgpuExt_setShadowVector(tfqmrgpuHandle_t handle, tfqmrgpuBs
  * (tfq_device.hpp), whatever the block order and however the columns are sharded over GPUs. */
 tfqmrgpuStatus_t tfqmrgpuExt_getShadowVector(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, float *v3);
 
+/* Debug getter for kernel-level parity tests: one of the solver's X-shaped work vectors as the last solve left it --
+ * which = 1: the solution X, 4 ... 9: v4 ... v9 in the reference's numbering (tfqmrgpu_core.hxx:52-59; v4 = A-image
+ * recurrence, v5 = residual-like vector, v6/v7 = search directions, v8 = A v6 of the second half step, v9 = A v6 of the
+ * first) -- to host memory, native layout [nnzbX][2][lm][ln], caller's block order, plan precision.  Non-destructive;
+ * call it before the next set/getMatrix, which stage the caller's blocks through v4 ... v9.
+ * After a solve that stopped at iteration k the vectors are those of the reference at the end of iteration k, except
+ * that the residual probe of this library does not overwrite v9 (the reference's does, tfqmrgpu_core.hxx:265). */
+tfqmrgpuStatus_t tfqmrgpuExt_getWorkVector(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, int which, void *values);
+
 /* ---- (3) stand-alone block-sparse multiply --------------------------------------------- */
 /* Y[iY] = sum over pairs p in [starts[iY], starts[iY+1]) of A[pairs[2p]] * X[pairs[2p+1]]
  * All pointers are DEVICE pointers.  Blocks are in the native layout RRRRIIII:

@@ -107,9 +107,11 @@ def spmm(precision, LM, LN, starts, pairs, A_nat, X_nat):
     return Y
 
 
-def solve(pr, precision="z", threshold=None, max_iterations=2000, transA="n", v3=None, plan=None, reduce=None):
+def solve(pr, precision="z", threshold=None, max_iterations=2000, transA="n", v3=None, plan=None, reduce=None, dump_iteration=None):
     """tfQMR on the CPU with the documented (CUDA-path) semantics of the reference.
-    v3: float array [nnzbX*2*LM*LN] (default: the glibc rand() sequence of the reference CPU path)."""
+    v3: float array [nnzbX*2*LM*LN] (default: the glibc rand() sequence of the reference CPU path).
+    dump_iteration: info["vectors"] = {1: x, 4: v4, ... 9: v9} (complex [nnzbX][LM][LN]) at the end of that iteration,
+    before its stopping test (tfqmrgpu_core.hxx:233)."""
     L = lib()
     real = np.float64 if precision == "z" else np.float32
     an = plan or analyse(pr)
@@ -125,12 +127,20 @@ def solve(pr, precision="z", threshold=None, max_iterations=2000, transA="n", v3
     cb = REDUCE_CB(reduce) if reduce else C.cast(None, REDUCE_CB)
     fn = L.tfqo_solve_z if precision == "z" else L.tfqo_solve_c
     fn.restype = C.c_int
+    hook = L.tfqo_set_dump_z if precision == "z" else L.tfqo_set_dump_c
+    hook.restype = None
+    dump = np.zeros((7,) + X.shape, dtype=real) if dump_iteration else None
+    if dump is not None:
+        hook(C.c_int(dump_iteration), _p(dump))
     st = fn(C.c_int(pr.LM), C.c_int(pr.LN), C.c_uint32(pr.nnzbX), C.c_uint32(pr.nnzbB), C.c_uint32(an["nCols"]),
             _p(an["starts"]), _p(an["pairs"]), _p(an["subset"]), _p(an["colindx"]),
             _p(A), _p(B), _p(v3), _p(X),
             C.c_double(pr.tolerance if threshold is None else threshold), C.c_int(max_iterations),
             C.byref(it), C.byref(res), C.byref(flops), _p(hist), C.byref(nh), cb, None)
     info = dict(iterations=it.value, residual=res.value, flops=flops.value, bound_history=hist[:nh.value].copy())
+    if dump is not None:
+        hook(C.c_int(0), None)
+        info["vectors"] = {w: from_native(dump[n]).astype(np.complex128) for n, w in enumerate((1, 4, 5, 6, 7, 8, 9))}
     return st, from_native(X).astype(np.complex128), info
 
 

@@ -198,6 +198,12 @@ void FN(tfqo_decT)(int LN, uint32_t nCols, int8_t *status, REAL *c67 /* may be N
     }
 }
 
+/* test hook (not in the reference): copy of the work vectors v1, v4 ... v9 as they stand at the end of iteration
+ * `iteration` (after :233, before the stopping test and its probe), [7][nnzbX*2*LM*LN]; NULL switches it off */
+static REAL *FN(dump_buf);
+static int FN(dump_iteration);
+void FN(tfqo_set_dump)(int iteration, REAL *buf) { FN(dump_iteration) = iteration; FN(dump_buf) = buf; }
+
 /* The tfQMR driver: restates tfqmrgpu::solve (tfqmrgpu_core.hxx:114-325) operation by operation.
  * v3 is supplied by the caller (the reference draws it at setBuffer time).
  * reduce (may be NULL): max-reduces doubles over ranks for the sharded mode (not in the reference).
@@ -256,6 +262,11 @@ int FN(tfqo_solve)(int LM, int LN, uint32_t nnzbX, uint32_t nnzbB, uint32_t nCol
         FN(tfqo_nrm2)(LM, LN, nnzbX, nCols, colindx, dvv, v5); nFlop += fNrm;               /* :228 */
         FN(tfqo_decT)(LN, nCols, status, NULL, eta, var, tau, alfa, dvv);                   /* :231 */
         FN(tfqo_axpy)(LM, LN, nnzbX, colindx, v1, v7, eta); nFlop += fAxp;                  /* :233 */
+
+        if (FN(dump_buf) && iteration == FN(dump_iteration)) {
+            REAL const *const vs[7] = {v1, v4, v5, v6, v7, v8, v9};
+            for (int v = 0; v < 7; ++v) memcpy(FN(dump_buf) + (size_t)v * nS, vs[v], nS * sizeof(REAL));
+        }
 
         /* stopping test on the residual bound (:239-260) */
         double red[2] = {0, 0}; /* {max tau/|b|^2, some RHS not broken down} */

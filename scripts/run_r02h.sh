@@ -1,6 +1,6 @@
 #!/bin/bash
 source scripts/gpu_steps.sh
-step 600 parity_report4.txt python scripts/parity_report.py
+step 600 parity_report4.txt python tests/parity_report.py
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 step 400 rocprof_bench.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02_stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline
 step 900 pmc_p2.log bash scripts/pmc_collect.sh gpurun_out/r02_pmc fd2d_16x16_z

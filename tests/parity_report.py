@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Observed deviations of the HIP path from the CPU oracle, per fixture: what the tolerances written into
 tests/test_gpu_parity.py are derived from (2 x the worst deviation seen).  Run on the GPU box:
-    python scripts/parity_report.py > gpurun_out/parity_report.txt"""
+    python tests/parity_report.py > gpurun_out/parity_report.txt"""
 import os
 import sys
 
@@ -9,7 +9,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import tfqmrgpu_amd as T  # noqa: E402
 from conftest import ALL_NAMES, golden_solves, load_golden, load_problem  # noqa: E402
 from oracle import pyoracle as O  # noqa: E402
@@ -58,3 +58,21 @@ for name, pr in cases:
         st, X, info = T.solve_problem(pr, prec, threshold=tol, max_iterations=300)
         st0, X0, info0 = O.solve(pr, prec, threshold=tol, max_iterations=300, v3=v3.reshape(-1))
         line("%s %s tol %.0e (hash)" % (name, prec, tol), st, info, st0, info0, X, X0)
+
+print("== work vectors after exactly k iterations (tests/test_gpu_hash_mode.py::test_work_vectors_after_k_iterations_match_the_oracle):")
+print("   max |v - v_oracle| / max |v_oracle| per vector (1 = x, 4 ... 9 = v4 ... v9)")
+import test_gpu_hash_mode as H  # noqa: E402
+for name, prec, _ in H.STATE_CASES:  # every k, also those the test skips
+    pr = H.CASES[name]()
+    v3 = T.hash_shadow_vector(pr).reshape(-1)
+    for k in H.STATE_ITERATIONS:
+        st0, X0, info0 = O.solve(pr, prec, threshold=1e-30, max_iterations=k, v3=v3, dump_iteration=k)
+        with T.Solver() as s:
+            s.create_plan(pr)
+            s.set_buffer(nbytes=s.buffer_size(pr.LM, pr.LN, prec))
+            s.set_matrix("A", pr.A, "n")
+            s.set_matrix("B", pr.B, "n")
+            st = s.solve(1e-30, k)
+            got = {w: s.get_work_vector(w) for w in (1, 4, 5, 6, 7, 8, 9)}
+        worst = {w: np.abs(got[w] - v).max() / np.abs(v).max() for w, v in info0["vectors"].items()}
+        print("%-16s %s k=%d st %d/%d  " % (name, prec, k, st, st0) + "  ".join("v%d %.1e" % (w, e) for w, e in worst.items()), flush=True)

@@ -35,7 +35,7 @@ def _tol(prec):
 
 # Rounding differences (MFMA summation order, FMA contraction, other reduction order) are amplified by the tfQMR
 # recurrences; how fast depends on the conditioning.  The tolerances below are 2 x the deviation OBSERVED on MI355X
-# against the oracle with the same (glibc) shadow vector (scripts/parity_report.py -> profiles/r02_parity_report.txt; the
+# against the oracle with the same (glibc) shadow vector (tests/parity_report.py -> profiles/r02_parity_report.txt; the
 # larger of the values seen with the round-1 and the round-2 multiply kernels),
 # per fixture: hist = whole per-iteration bound history (relative), half = its first half, res = final residual
 # (relative).  The north star's "residuals matching to 1e-6 relative" holds on every fixture whose final residual sits

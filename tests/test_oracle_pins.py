@@ -109,3 +109,18 @@ def test_against_live_reference(oracle):
         assert (st, info["iterations"]) == (st2, info2["iterations"])
         assert info["flops"] == info2["flops"]
         assert np.abs(X - X2).max() <= (1e-12 if prec == "z" else 1e-5) * np.abs(X2).max()
+
+
+def test_state_dump_hook(oracle):
+    # the test hook behind tests/test_gpu_hash_mode.py::test_work_vectors_after_k_iterations...: the dumped vectors are the
+    # driver's own (x of the dump = the X handed back; v9 = A v6 - (v6 changed since) is not checkable, v8 = A v6 is)
+    pr = load_problem("fd_16x16_2d")
+    st, X, info = oracle.solve(pr, "z", threshold=1e-30, max_iterations=3, dump_iteration=3)
+    st2, X2, info2 = oracle.solve(pr, "z", threshold=1e-30, max_iterations=3)
+    assert st == st2 == 9 and np.array_equal(X, X2) and "vectors" not in info2
+    v = info["vectors"]
+    assert sorted(v) == [1, 4, 5, 6, 7, 8, 9] and np.array_equal(v[1], X)
+    an = oracle.analyse(pr)
+    real = np.float64
+    Y = oracle.spmm("z", pr.LM, pr.LN, an["starts"], an["pairs"], oracle.a_native(pr.A, real), oracle.to_native(v[6], real))
+    assert np.array_equal(oracle.from_native(Y), v[8])        # v8 = A v6 (tfqmrgpu_core.hxx:224), same routine, same bits

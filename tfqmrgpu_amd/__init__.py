@@ -33,7 +33,7 @@ EXT_SYMBOLS = [  # include/tfqmrgpu_ext.h
     "tfqmrgpuExt_planView", "tfqmrgpuExt_getBoundHistory", "tfqmrgpuExt_setProfiling", "tfqmrgpuExt_getProfile",
     "tfqmrgpuExt_getProfileGated",
     "tfqmrgpuExt_setShadowMode",
-    "tfqmrgpuExt_setShadowVector", "tfqmrgpuExt_getShadowVector", "tfqmrgpuExt_multiply", "tfqmrgpuExt_applyOperator", "tfqmrgpuExt_shardColumns",
+    "tfqmrgpuExt_setShadowVector", "tfqmrgpuExt_getShadowVector", "tfqmrgpuExt_getWorkVector", "tfqmrgpuExt_multiply", "tfqmrgpuExt_applyOperator", "tfqmrgpuExt_shardColumns",
     "tfqmrgpuExt_freeShard", "tfqmrgpuExt_commUniqueId", "tfqmrgpuExt_commInit",
     "tfqmrgpuExt_commDestroy", "tfqmrgpuExt_setReduceCallback", "tfqmrgpuExt_setOperator",
 ]
@@ -115,6 +115,7 @@ def load_library(path=LIB_PATH):
     lib.tfqmrgpuExt_setShadowMode.argtypes = [P, I]
     lib.tfqmrgpuExt_setShadowVector.argtypes = [P, P, P]
     lib.tfqmrgpuExt_getShadowVector.argtypes = [P, P, P]
+    lib.tfqmrgpuExt_getWorkVector.argtypes = [P, P, C.c_int, P]
     lib.tfqmrgpuExt_multiply.argtypes = [P, C.c_char, I, I, C.c_uint32, P, P, P, P, P]
     lib.tfqmrgpuExt_applyOperator.argtypes = [P, P, I]
     lib.tfqmrgpuExt_shardColumns.argtypes = [I, P, I, P, P, I, P, I, I, I, C.POINTER(Shard)]
@@ -238,6 +239,12 @@ class Solver:
         v3 = np.zeros((self.problem.nnzbX, 2, self.LM, self.LN), dtype=np.float32)
         _check(lib.tfqmrgpuExt_getShadowVector(self.handle, self.plan, _ptr(v3)), "tfqmrgpuExt_getShadowVector")
         return v3
+
+    def get_work_vector(self, which):
+        """work vector `which` (1: X, 4 ... 9: v4 ... v9, tfqmrgpu_core.hxx:52-59) as the last solve left it: complex [nnzbX, LM, LN]"""
+        v = np.zeros((self.problem.nnzbX, 2, self.LM, self.LN), dtype=self._real_dtype())
+        _check(lib.tfqmrgpuExt_getWorkVector(self.handle, self.plan, which, _ptr(v)), "tfqmrgpuExt_getWorkVector")
+        return v[:, 0].astype(np.float64) + 1j * v[:, 1]
 
     # -- values ----------------------------------------------------------------------------------------
     def _real_dtype(self):

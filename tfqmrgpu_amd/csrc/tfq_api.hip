@@ -83,9 +83,9 @@ static Stage stage_of(Plan const& p) {
 
 // move blocks between a host array in the caller's layout and a native device array
 static tfqmrgpuStatus_t transfer_blocks(Plan& p, hipStream_t s, int direction, bool dbl, void* native,
-    void* host, uint32_t const* u2n, uint32_t nBlocks, int nR, int nC, int layout, bool trans, bool conj)
+    void* host, uint32_t const* u2n, uint32_t nBlocks, int nR, int nC, int layout, bool trans, bool conj, Stage const* own = nullptr)
 {
-    Stage const st = stage_of(p);
+    Stage const st = own ? *own : stage_of(p);
     size_t const blockBytes = size_t(2) * nR * nC * (dbl ? 8 : 4);
     size_t const cap = st.bytes / blockBytes;
     if (cap < 1) return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED);
@@ -805,6 +805,27 @@ tfqmrgpuStatus_t tfqmrgpuExt_getShadowVector(tfqmrgpuHandle_t handle, tfqmrgpuBs
     DevPlan const d = resolve(*p);
     return transfer_blocks(*p, (hipStream_t)h->stream, 1, false, d.v3, (void*)v3, d.u2i, p->nnzbX, p->LM, p->LN,
                            TFQMRGPU_LAYOUT_RRRRIIII, false, false);
+}
+
+tfqmrgpuStatus_t tfqmrgpuExt_getWorkVector(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, int which, void* values) {
+    auto p = asPlan(plan); auto h = (Handle*)handle;
+    if (!p || !h || !values || !p->buffer) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    if ('z' != p->precision && 'c' != p->precision) return err(TFQMRGPU_PRECISION_MISSMATCH, __LINE__ % 10000, p->precision);
+    DevPlan const d = resolve(*p);
+    void* v = nullptr;
+    switch (which) {
+        case 1: v = d.x; break;  case 4: v = d.v4; break;  case 5: v = d.v5; break;  case 6: v = d.v6; break;
+        case 7: v = d.v7; break; case 8: v = d.v8; break;  case 9: v = d.v9; break;
+        default: return err(TFQMRGPU_VARIABLENAME_UNKNOWN, __LINE__ % 10000, char('0' + (which & 7)));
+    }
+    // the usual staging area IS the work vectors: this getter brings its own
+    Stage st{nullptr, std::min<size_t>(p->S, size_t(64) << 20)};
+    st.bytes = std::max(st.bytes, size_t(2) * p->LM * p->LN * ('z' == p->precision ? 8 : 4));
+    if (hipSuccess != hipMalloc((void**)&st.ptr, st.bytes)) return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED);
+    auto const status = transfer_blocks(*p, (hipStream_t)h->stream, 1, 'z' == p->precision, v, values, d.u2i, p->nnzbX, p->LM, p->LN,
+                                        TFQMRGPU_LAYOUT_RRRRIIII, false, false, &st);
+    (void)hipFree(st.ptr);
+    return status;
 }
 
 tfqmrgpuStatus_t tfqmrgpuExt_multiply(tfqmrgpuHandle_t handle, char precision, int lm, int ln,
