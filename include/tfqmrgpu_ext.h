@@ -70,8 +70,10 @@ tfqmrgpuStatus_t tfqmrgpuExt_setShadowMode(tfqmrgpuBsrsvPlan_t plan, int mode);
 /* user-supplied v3, host array float[nnzbX][2][LM][LN] in the caller's BSR order; call after setBuffer */
 tfqmrgpuStatus_t tfqmrgpuExt_setShadowVector(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, float const *v3);
 /* the vector in use, same shape and order (for parity tests: feed it to a CPU implementation); call after setBuffer,
- * not during a solve.  In hash mode element e of the block in block row r, ORIGINAL block column c (0-based) is
- *   float((splitmix64(key + e * 0xd1342543de82ef95) >> 40) + 1) / 2^24,  key = splitmix64(c << 32 | r) ^ 1234
+ * not during a solve.  In hash mode the four reals (Re, Im) x (row 2m, row 2m+1) of column j of the block in block row r,
+ * ORIGINAL block column c (0-based) come from one 64-bit hash, 16 bits each:
+ *   h = splitmix64(key + (m * ln + j) * 0xd1342543de82ef95),  key = splitmix64(c << 32 | r) ^ 1234,
+ *   value = float(((h >> 16 * (2 * (row & 1) + (Im ? 1 : 0))) & 0xffff) + 1) / 2^16   in (0, 1]
  * (tfq_device.hpp), whatever the block order and however the columns are sharded over GPUs. */
 tfqmrgpuStatus_t tfqmrgpuExt_getShadowVector(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, float *v3);
 

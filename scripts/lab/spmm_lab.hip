@@ -3,6 +3,11 @@
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form=1 -Iinclude -Itfqmrgpu_amd/csrc scripts/lab/spmm_lab.hip -o scripts/bin/spmm_lab
 // usage: spmm_lab <plan dir> <epi 1|2> <variant> [reps]
 #include "../../tfqmrgpu_amd/csrc/tfq_spmm.hip"
+// the lab kernels keep the one-hash-per-real shadow vector they were measured with (the product moved to shadow_quad)
+namespace tfq { __host__ __device__ inline float shadow_value(uint64_t key, uint32_t e) {
+    uint64_t const h = splitmix64(key + uint64_t(e) * 0xd1342543de82ef95ull);
+    return float((h >> 40) + 1) * (1.f / 16777216.f);
+} }
 
 #include <algorithm>
 #include <cstdio>

@@ -43,9 +43,10 @@ for name in ALL_NAMES:
         line("%s %s tol %.0e" % (name, prec, tol), st, info, st0, info0, X, X0)
 
 print("== hash shadow vector (the default, the benchmarked kernels), oracle fed with the same vector")
+import test_gpu_hash_mode as H  # noqa: E402
 cases = [(n, load_problem(n)) for n in ALL_NAMES]
+cases += [(n, make()) for n, make in sorted(H.CASES.items()) if n not in ALL_NAMES]     # the synthetic cases of the hash-mode tests
 cases += [("cfg3 small 13-point 32x32", PR.stencil_2d(8, 8, 32, 32, 2, seed=3, points=13)),
-          ("st 16x16 12x12 4 columns", PR.stencil_2d(12, 12, 16, 16, 4, seed=7)),
           ("st 8x8 12x12 4 columns", PR.stencil_2d(12, 12, 8, 8, 4, seed=5))]
 for name, pr in cases:
     for prec in "zc":
@@ -61,7 +62,6 @@ for name, pr in cases:
 
 print("== work vectors after exactly k iterations (tests/test_gpu_hash_mode.py::test_work_vectors_after_k_iterations_match_the_oracle):")
 print("   max |v - v_oracle| / max |v_oracle| per vector (1 = x, 4 ... 9 = v4 ... v9)")
-import test_gpu_hash_mode as H  # noqa: E402
 for name, prec, _ in H.STATE_CASES:  # every k, also those the test skips
     pr = H.CASES[name]()
     v3 = T.hash_shadow_vector(pr).reshape(-1)

@@ -47,7 +47,8 @@ def _check_solution_on_device(torch, oracle, pr, prec, X, info, tol):
         worst = float(torch.sqrt((res2 / b2).max()).item())
         assert worst <= tol, worst
         # the solver's own figure is computed in the storage precision with its own summation order
-        assert worst == pytest.approx(info["residual"], rel=1e-6 if prec == "z" else 2e-2)
+        # (rounding of A x at |r| / |b| = 1e-10 is ~1e-6 of the residual; not pytest.approx, whose default absolute 1e-12 would decide)
+        assert abs(worst - info["residual"]) <= (1e-4 if prec == "z" else 2e-2) * info["residual"], (worst, info["residual"])
         del R, Bc
         Z = torch.randn_like(Xn)
         Y2, Y3 = torch.zeros_like(Xn), torch.zeros_like(Xn)

@@ -46,18 +46,22 @@ def test_device_shadow_vector_is_the_documented_hash(name):
 
 # Tolerances = 2 x the deviation observed on MI355X (tests/parity_report.py -> profiles/r02_parity_report.txt) between
 # the HIP path and the oracle fed with the same vector: (whole bound history, its first half, final residual), relative.
-# Everything that ends at the threshold agrees to better than 1e-6; the 3-D Poisson system at energy 0 (fd_8x8_3d)
-# sheds 8 digits per iteration at the end, there the first half of the history is what can be compared tightly.
+# How far rounding differences are amplified depends on the shadow vector; each entry is the larger of the values seen
+# with the two hash definitions this library has had (one hash per real until mid round 2 | one per four reals).
+# Everything that ends at the threshold agrees to about 1e-6 (a residual of 1e-10 |b| is itself only known to ~1e-6: eps |A||x| / |r|);
+# the 3-D Poisson system at energy 0 (fd_8x8_3d) sheds 8 digits per iteration at the end, there the first half of the
+# history is what can be compared tightly.
 Z_TOL = {
-    "fd_16x16_2d": (2e-10, 3e-11, 2e-7),      # observed 6.4e-11 / 1.2e-11 / 8.6e-8
-    "fd_16x16_small": (3e-10, 2e-11, 2e-6),   # 1.1e-10 / 5.8e-12 / 7.6e-7
-    "dense_random": (1e-10, 2e-12, 1e-4),     # 2.4e-11 / 6.9e-13 / 4.6e-5 (the residual 4e-12 is rounding noise)
-    "stencil_8x8": (1e-10, 1e-12, 1e-6),      # 9.7e-12 / 6.0e-14 / 4.3e-7
-    "stencil_8x32": (1e-10, 2e-11, 1e-5),     # 5.8e-12 / 5.8e-12 / 4.8e-6
-    "st16x16": (2e-10, 2e-12, 3e-6),          # 5.2e-11 / 7.8e-13 / 1.1e-6
-    "st16x16_ragged": (1e-6, 1e-6, 1e-6), "st32x32": (1e-6, 1e-6, 1e-6),   # not in the report: the north star's 1e-6
-    "fd_8x8_3d": (1.2, 2e-8, 0.14),           # 5.7e-1 / 6.6e-9 / 6.7e-2
-    "fd_4x4_2d": (2e-6, 2e-9, 3e-7),          # 9.9e-7 / 6.2e-10 / 1.4e-7
+    "fd_16x16_2d": (2e-10, 3e-11, 1.3e-6),    # observed 6.5e-11 / 1.2e-11 / 6.2e-7
+    "fd_16x16_small": (3e-10, 1e-10, 2e-6),   # 1.1e-10 / 4.8e-11 / 7.6e-7
+    "dense_random": (1e-10, 2e-12, 1e-4),     # 4.4e-11 / 6.9e-13 / 4.6e-5 (the residual 4e-12 is rounding noise)
+    "stencil_8x8": (1e-10, 2e-12, 1e-6),      # 9.7e-12 / 6.6e-13 / 4.3e-7
+    "stencil_8x32": (1e-10, 2e-11, 1e-5),     # 1.1e-11 / 5.8e-12 / 4.8e-6
+    "st16x16": (2e-10, 2e-12, 3e-6),          # 5.2e-11 / 9.7e-13 / 1.1e-6
+    "st16x16_ragged": (1e-11, 1e-12, 1e-7),   # 1.8e-12 / 1.2e-13 / 3.8e-8
+    "st32x32": (2e-11, 1e-12, 1e-7),          # 7.3e-12 / 2.2e-14 / 3.4e-9
+    "fd_8x8_3d": (1.2, 2e-8, 0.55),           # 5.7e-1 / 6.6e-9 / 2.6e-1
+    "fd_4x4_2d": (8e-6, 2e-9, 1.2e-5),        # 3.7e-6 / 6.2e-10 / 6.0e-6
 }
 
 
@@ -75,7 +79,7 @@ def test_hash_mode_takes_the_oracles_trajectory_z(oracle, name):
     half = (len(h0) + 1) // 2
     assert len(h) == len(h0) and np.allclose(h, h0, rtol=htol, atol=0), np.abs(h / h0 - 1).max()
     assert np.allclose(h[:half], h0[:half], rtol=half_tol, atol=0), np.abs(h[:half] / h0[:half] - 1).max()
-    assert info["residual"] == pytest.approx(info0["residual"], rel=rtol)
+    assert abs(info["residual"] - info0["residual"]) <= rtol * info0["residual"], info["residual"] / info0["residual"] - 1   # (not pytest.approx: abs 1e-12)
     assert np.abs(X - X0).max() <= 1e-7 * np.abs(X0).max()
 
 
@@ -141,14 +145,16 @@ def test_tuning_switches_change_code_paths_not_results(tmp_path, name, prec, tol
 # the decision kernels.  tfqmrgpuExt_getWorkVector hands them out; the oracle (fed with the same shadow vector) dumps
 # its own at the end of the same iteration (tfqmrgpu_core.hxx:189-233).  A bug in a fused kernel that cancelled over an
 # iteration would show here in the vector it writes.  Bounds per k = 4 x the worst deviation observed on MI355X
-# (tests/parity_report.py -> profiles/r02_parity_report.txt): after one iteration every vector agrees to 14 digits (6
-# in float); later the recurrences amplify the rounding differences while the vectors themselves shrink with the residual
+# (tests/parity_report.py -> profiles/r02_parity_report.txt, both hash definitions): after one iteration every vector agrees to
+# 14 digits (5 in float); later the recurrences amplify the rounding differences while the vectors themselves shrink with the residual
 # (st32x32 converges by two digits per iteration: in float its vectors are rounding noise at k = 5, not compared).
-Z_STATE = {1: 6e-14, 2: 2e-10, 5: 1e-9}       # observed 1.4e-14 (st16x16_ragged) / 3.6e-11 (stencil_8x32) / 2.4e-10 (st32x32, stencil_8x32)
+Z_STATE = {1: 7e-14, 2: 2e-10, 5: 1e-9}       # observed 1.6e-14 (st16x16_ragged) / 3.6e-11 (stencil_8x32) / 2.4e-10 (st32x32, stencil_8x32)
 STATE_CASES = [("fd_16x16_2d", "z", Z_STATE), ("st16x16_ragged", "z", Z_STATE), ("stencil_8x8", "z", Z_STATE), ("stencil_8x32", "z", Z_STATE),
                ("st32x32", "z", Z_STATE), ("fd_4x4_2d", "z", Z_STATE),
-               ("fd_16x16_2d", "c", {1: 1.2e-6, 2: 8e-5, 5: 7e-2}),     # observed 2.7e-7 / 1.9e-5 / 1.7e-2
-               ("st32x32", "c", {1: 2.4e-5, 2: 1.2e-2})]               # observed 5.8e-6 / 2.9e-3
+               # float: a dot product with the shadow vector that cancels amplifies the 1e-7 differences of v4 / v5 into alfa, beta
+               # and from there into x (seen at k = 2 with the second hash definition: x 1.1e-3, gone again at k = 5)
+               ("fd_16x16_2d", "c", {1: 1.2e-6, 2: 5e-3, 5: 7e-2}),     # observed 2.7e-7 / 1.1e-3 / 1.7e-2
+               ("st32x32", "c", {1: 6e-5, 2: 1.2e-2})]                 # observed 1.3e-5 / 2.9e-3
 STATE_ITERATIONS = [1, 2, 5]
 
 

@@ -44,7 +44,7 @@ def _tol(prec):
 # per step) or the blocks are 4x4 (longer sums in another order) the END of the trajectory differs more and the table
 # says by how much; the first half of the history agrees to 1e-7 everywhere.
 Z_TOL = {
-    "fd_16x16_2d":       dict(hist=2e-10, half=4e-11, res=2e-7),    # observed 8.8e-11 / 2.0e-11 / 5.4e-8
+    "fd_16x16_2d":       dict(hist=2e-10, half=4e-11, res=3e-7),    # observed 8.8e-11 / 2.0e-11 / 1.1e-7
     "fd_16x16_small":    dict(hist=3e-10, half=3e-11, res=3e-7),    # 1.4e-10 / 1.1e-11 / 1.4e-7
     "dense_random":      dict(hist=3e-10, half=2e-12, res=5e-7),    # 1.1e-10 / 6.8e-13 / 2.3e-7
     "stencil_8x8":       dict(hist=1e-11, half=1e-12, res=2e-6),    # 9.5e-13 / 1.7e-13 / 1.0e-6
@@ -90,8 +90,9 @@ def test_solve_matches_oracle_and_golden(oracle, name):
             half = (len(h) + 1) // 2
             assert np.allclose(h[:half], h0[:half], rtol=t["half"], atol=0), (name, np.abs(h[:half] / h0[:half] - 1).max())
             assert np.allclose(h, h0, rtol=t["hist"], atol=0), (name, np.abs(h / h0 - 1).max())
-            assert info["residual"] == pytest.approx(info0["residual"], rel=t["res"]), name
-            assert info["residual"] == pytest.approx(float(g[tag + "residual"]), rel=t["res"]), name
+            # (not pytest.approx: its default absolute tolerance of 1e-12 would swallow residuals of 1e-10)
+            assert abs(info["residual"] - info0["residual"]) <= t["res"] * info0["residual"], (name, info["residual"] / info0["residual"] - 1)
+            assert abs(info["residual"] - float(g[tag + "residual"])) <= t["res"] * float(g[tag + "residual"]), name
         else:
             d = abs(info["iterations"] - info0["iterations"])
             assert d <= C_TOL[name]["it"], "%s: %d against %d iterations in complex<float>: the float trajectories separate (see C_TOL)" % (
@@ -380,7 +381,8 @@ def test_large_problem_properties(torch_cuda, oracle):
         b2 = np.zeros((an["nCols"], pr.LN))
         np.add.at(b2, col[an["subset"]], (np.abs(pr.B) ** 2).sum(axis=1))
         assert np.sqrt((res2 / b2).max()) <= 1e-9
-        assert np.sqrt((res2 / b2).max()) == pytest.approx(info["residual"], rel=1e-6)
+        # the solver's own figure, against this re-computation with another summation order (rounding of A x at |r| / |b| = 1e-10: ~1e-6)
+        assert abs(np.sqrt((res2 / b2).max()) - info["residual"]) <= 1e-4 * info["residual"]
         Z = torch.randn_like(Xn)
         Y2, Y3 = torch.zeros_like(Xn), torch.zeros_like(Xn)
         mult(Z, Y2)

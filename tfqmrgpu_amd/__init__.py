@@ -346,16 +346,20 @@ class Solver:
 
 
 def hash_shadow_vector(pr):
-    """numpy restatement of the library's default shadow vector (tfq_device.hpp: shadow_key / shadow_value), float
+    """numpy restatement of the library's default shadow vector (tfq_device.hpp: shadow_key / shadow_quad / shadow_pick), float
     [nnzbX, 2, LM, LN] in the caller's block order -- what tests feed to the CPU oracle"""
     from .problems import _splitmix64
     rows = np.repeat(np.arange(pr.mb, dtype=np.uint64), np.diff(pr.rowPtrX))
     cols = (pr.colIndX.astype(np.int64) - pr.index_offset).astype(np.uint64)
     with np.errstate(over="ignore"):
         key = _splitmix64((cols << np.uint64(32)) | rows) ^ np.uint64(1234)
-        e = np.arange(2 * pr.LM * pr.LN, dtype=np.uint64) * np.uint64(0xD1342543DE82EF95)
-        h = _splitmix64(key[:, None] + e[None, :])
-    v = ((h >> np.uint64(40)) + np.uint64(1)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+        q = np.arange((pr.LM // 2) * pr.LN, dtype=np.uint64) * np.uint64(0xD1342543DE82EF95)   # one hash per (pair of rows m, column c)
+        h = _splitmix64(key[:, None] + q[None, :]).reshape(pr.nnzbX, pr.LM // 2, pr.LN)
+    v = np.empty((pr.nnzbX, 2, pr.LM // 2, 2, pr.LN), dtype=np.float32)
+    for odd in range(2):
+        for plane in range(2):       # 16 bits each: (row 2m | 2m + 1) x (Re | Im)
+            bits = (h >> np.uint64(16 * (2 * odd + plane))) & np.uint64(0xFFFF)
+            v[:, plane, :, odd, :] = (bits + np.uint64(1)).astype(np.float32) * np.float32(1.0 / 65536.0)
     return v.reshape(pr.nnzbX, 2, pr.LM, pr.LN)
 
 

@@ -68,10 +68,18 @@ __host__ __device__ inline uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 __host__ __device__ inline uint64_t shadow_key(uint32_t origCol, uint32_t row) { return splitmix64((uint64_t(origCol) << 32) | uint64_t(row)) ^ 1234u; }
-// e: index of the element in the block, [Re | Im][LM][LN]
-__host__ __device__ inline float shadow_value(uint64_t key, uint32_t e) {
-    uint64_t const h = splitmix64(key + uint64_t(e) * 0xd1342543de82ef95ull);
-    return float((h >> 40) + 1) * (1.f / 16777216.f);   // 24 random bits -> (0, 1]
+// One 64-bit hash serves the four reals of a pair of rows: 16 bits each for (row 2m | 2m + 1) x (Re | Im) of column c of the block.
+// (Round 1 and the first half of round 2 drew one hash per real: the 64-bit arithmetic cost the fused multiplies 1-6 %,
+// profiles/r02_ab_hash.txt; the lanes of the interleaved kernels hold exactly these four values.)
+__host__ __device__ inline uint64_t shadow_quad(uint64_t key, uint32_t m, uint32_t c, uint32_t LN) {
+    return splitmix64(key + uint64_t(m * LN + c) * 0xd1342543de82ef95ull);
+}
+__host__ __device__ inline float shadow_pick(uint64_t h, int oddRow, int plane) {
+    return float((uint32_t(h >> (16 * (2 * oddRow + plane))) & 0xffffu) + 1u) * (1.f / 65536.f);   // 16 random bits -> (0, 1]
+}
+// element (plane = Re | Im, row r, column c) of the block
+__host__ __device__ inline float shadow_value(uint64_t key, int plane, uint32_t r, uint32_t c, uint32_t LN) {
+    return shadow_pick(shadow_quad(key, r >> 1, c, LN), int(r & 1), plane);
 }
 #endif
 

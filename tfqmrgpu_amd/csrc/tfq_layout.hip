@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_shadow_hash(DevPlan d) {
         int const P = d.LM * d.LN;
         for (int e = threadIdx.x; e < E; e += 256) {   // e = logical element [Re|Im][row][column], stored where the plan's element order puts it
             int const c = e / P, r = (e % P) / d.LN, q = e % d.LN;
-            v[c * P + plane_offset(d.ilv, r, q, d.LN)] = shadow_value(key, uint32_t(e));
+            v[c * P + plane_offset(d.ilv, r, q, d.LN)] = shadow_value(key, c, uint32_t(r), uint32_t(q), uint32_t(d.LN));
         }
     }
 }

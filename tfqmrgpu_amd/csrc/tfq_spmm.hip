@@ -378,7 +378,7 @@ struct EpiOps {
 
 // epilogue for VW neighbouring elements at `off` (same arithmetic per element as epilogue<> above); the elements
 // are columns n0 .. n0 + VW - 1 of the NT columns of the lane (per-RHS scalars sr/si and partial sums are per column)
-template <typename R, int EPI, int VW, int NPL, int NT, bool HASH = false>
+template <typename R, int EPI, int VW, int NPL, int NT, bool HASH = false, int LN = 16>
 __device__ inline void epilogue_row(SpmmArgs const& a, size_t off, int P, R const (&yr)[VW], R const (&yi)[VW],
                                     R const (&sr)[NT], R const (&si)[NT], int n0, EpiOps<R, EPI, VW, HASH> const& o,
                                     uint32_t bq, int eoff, double (&part)[NPL > 0 ? NPL : 1][NT], uint64_t key)
@@ -396,7 +396,7 @@ __device__ inline void epilogue_row(SpmmArgs const& a, size_t off, int P, R cons
                 nr[n] = cr * yr[n] - ci * yi[n] + o.ur[n]; ni[n] = ci * yr[n] + cr * yi[n] + o.ui[n];
             }
             double wr, wi;   // the shadow vector: read, or recomputed from its hash (tfq_device.hpp)
-            if constexpr (HASH) { wr = shadow_value(key, uint32_t(eoff + n)); wi = shadow_value(key, uint32_t(P + eoff + n)); }
+            if constexpr (HASH) { uint64_t const hq = shadow_quad(key, uint32_t(eoff + n) / (2 * LN), uint32_t(eoff + n) % LN, LN); int const odd = (uint32_t(eoff + n) / LN) & 1; wr = shadow_pick(hq, odd, 0); wi = shadow_pick(hq, odd, 1); }
             else { wr = o.wr[n]; wi = o.wi[n]; }
             double const dr = nr[n], di = ni[n];
             part[0][n0 + n] += dr * wr - di * wi;
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at leas
                         } else { yr[n] = cre[ms][g * VW + n][r]; yi[n] = cim[ms][g * VW + n][r]; }
                     }
                     if constexpr (!PRE) ops[0].load(a, off, P);
-                    epilogue_row<R, EPI, VW, NPL, NT, HASH>(a, off, P, yr, yi, sr, si, g * VW, ops[PRE ? (ms * 4 + r) * NG + g : 0], bq, e, part, key);
+                    epilogue_row<R, EPI, VW, NPL, NT, HASH, LN>(a, off, P, yr, yi, sr, si, g * VW, ops[PRE ? (ms * 4 + r) * NG + g : 0], bq, e, part, key);
                 }
     }
 
@@ -671,6 +671,8 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
         }
         if (q < q1) mma(o0);
 
+        uint64_t hq[2] = {0, 0};   // the shadow vector recomputed: one hash per pair of rows (tfq_device.hpp: shadow_quad)
+        if constexpr (HASH) { hq[0] = shadow_quad(key, uint32_t(lr), uint32_t(lc), LN); hq[1] = shadow_quad(key, uint32_t(lr + 4), uint32_t(lc), LN); }
         uint32_t bq = 0xffffffffu;
         if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
 #pragma unroll
@@ -696,9 +698,8 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
                     ni[e] = __builtin_fma(sr, yi[e], __builtin_fma(si, yr[e], ui[h][e]));
                 }
                 if constexpr (UPD) {
-                    int const row = 2 * (lr + 4 * h) + e;       // the logical element (row, lc): what the shadow vector's hash is defined on
-                    double w0, w1;
-                    if constexpr (HASH) { w0 = shadow_value(key, uint32_t(row * LN + lc)); w1 = shadow_value(key, uint32_t(P + row * LN + lc)); }
+                    double w0, w1;      // the logical elements (rows 2 (lr + 4 h) + e, column lc) are one quad of the shadow vector's hash
+                    if constexpr (HASH) { w0 = shadow_pick(hq[h], e, 0); w1 = shadow_pick(hq[h], e, 1); }
                     else { w0 = wr[h][e]; w1 = wi[h][e]; }
                     double const dr = nr[e], di = ni[e];
                     part[0] = __builtin_fma(-di, w1, __builtin_fma(dr, w0, part[0]));
@@ -808,6 +809,8 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
         }
         if (q < q1) mma(o0);
 
+        uint64_t hq[2] = {0, 0};   // the shadow vector recomputed: one hash per pair of rows (tfq_device.hpp: shadow_quad)
+        if constexpr (HASH) { hq[0] = shadow_quad(key, uint32_t(2 * lr), uint32_t(lc), LN); hq[1] = shadow_quad(key, uint32_t(2 * lr + 1), uint32_t(lc), LN); }
         f4v yr, yi, nr, ni;
         f4v br = f4v{0, 0, 0, 0}, bi = f4v{0, 0, 0, 0};
         if constexpr (EPI == EPI_RESIDUAL) {
@@ -828,9 +831,8 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
                 ni[e] = __builtin_fmaf(sr, yi[e], __builtin_fmaf(si, yr[e], ui[e]));
             }
             if constexpr (UPD) {
-                int const row = 4 * lr + e;
-                double w0, w1;
-                if constexpr (HASH) { w0 = shadow_value(key, uint32_t(row * LN + lc)); w1 = shadow_value(key, uint32_t(P + row * LN + lc)); }
+                double w0, w1;          // rows 4 lr + e of column lc: two quads of the shadow vector's hash
+                if constexpr (HASH) { w0 = shadow_pick(hq[e >> 1], e & 1, 0); w1 = shadow_pick(hq[e >> 1], e & 1, 1); }
                 else { w0 = wr[e]; w1 = wi[e]; }
                 double const dr = nr[e], di = ni[e];
                 part[0] = __builtin_fma(-di, w1, __builtin_fma(dr, w0, part[0]));
@@ -938,11 +940,9 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8(SpmmArgs a) {
             d2v nr, ni;
             d2v w0, w1;     // the shadow vector: Re and Im of the two elements
             if constexpr (HASH) {
+                uint64_t const hq = shadow_quad(key, uint32_t(lr), uint32_t(j), LN);   // rows 2 lr, 2 lr + 1 of column j
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    int const row = 2 * lr + e;
-                    w0[e] = shadow_value(key, uint32_t(row * LN + j)); w1[e] = shadow_value(key, uint32_t(P + row * LN + j));
-                }
+                for (int e = 0; e < 2; ++e) { w0[e] = shadow_pick(hq, e, 0); w1[e] = shadow_pick(hq, e, 1); }
             } else {
                 f2v const wO = f2v{__shfl_xor(wM[0], 8), __shfl_xor(wM[1], 8)};
                 w0 = cp ? d2v{wO[0], wO[1]} : d2v{wM[0], wM[1]}; w1 = cp ? d2v{wM[0], wM[1]} : d2v{wO[0], wO[1]};
