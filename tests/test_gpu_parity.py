@@ -299,6 +299,31 @@ def test_one_call_driver(prec):
     assert T.decode(st) == (12, 3, 3)
 
 
+def test_profiling_levels_change_no_result():
+    """tfqmrgpuExt_setProfiling: 1 = HIP events around every kernel class, 2 = only around the two fused multiplies (what
+    bench.py keeps inside its timed region); the events never change what is computed"""
+    pr = load_problem("fd_16x16_2d")
+    with T.Solver() as s:
+        s.create_plan(pr)
+        s.set_buffer(nbytes=s.buffer_size(16, 16, "z"))
+        s.set_matrix("A", pr.A)
+        s.set_matrix("B", pr.B)
+        got = {}
+        for level in (0, 1, 2):
+            s.set_profiling(level)
+            assert s.solve(1e-9, 2000) == 0
+            got[level] = (s.get_info()["iterations"], s.get_matrix(), s.profile(), s.profile(gated=True))
+        it = got[0][0]
+        assert got[1][0] == got[2][0] == it and np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][1], got[2][1])
+        assert all(n == 0 for n, _ in got[0][2].values())
+        for k, (n, ms) in got[1][2].items():
+            assert (n == it or k == "probe") and ms > 0, k            # every class once per iteration, probes when requested
+        for k, (n, ms) in got[2][2].items():
+            assert (n, ms > 0) == ((it, True) if k in ("spmm_v4_dot", "spmm_v5_nrm_dot") else (0, False)), k
+        # launches enqueued ahead of the stopping decision return at once: counted apart, same number in both levels
+        assert got[1][3]["spmm_v4_dot"][0] == got[2][3]["spmm_v4_dot"][0]
+
+
 def test_plan_reuse_and_status_codes():
     pr = load_problem("fd_16x16_small")
     with T.Solver() as s:

@@ -247,7 +247,9 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
     hipEvent_t ev[DEPTH];
     for (int i = 0; i < DEPTH; ++i) ev[i] = (hipEvent_t)p.ringEvent[i];
     // profiling: NK+1 timing events per in-flight iteration, event k sits in front of kernel class k
-    bool const prof = p.profiling;
+    int const prof = p.profiling;
+    // level 2: only the fused multiplies are bracketed (class k needs events k and k + 1)
+    auto const timed = [prof](int k) { return 1 == prof || (2 == prof && (TFQMRGPU_PROF_SPMM_V4_DOT == k || TFQMRGPU_PROF_SPMM_V5_NRM_DOT == k)); };
     EventList pev;
     if (prof && !pev.create(size_t(DEPTH) * (NK + 1))) return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED);
     for (int k = 0; k < NK; ++k) { p.profLaunches[k] = 0; p.profMs[k] = 0; p.profGatedLaunches[k] = 0; p.profGatedMs[k] = 0; }
@@ -298,7 +300,10 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         if (st && !fail) fail = st;
     };
     auto launches = [&](int slot, int part) {
-        auto mark = [&](int k) { if (prof && hipSuccess != hipEventRecord(pev[slot * (NK + 1) + k], s) && !fail) fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED); };
+        auto mark = [&](int k) {
+            if (!(k < NK && timed(k)) && !(k > 0 && timed(k - 1))) return;
+            if (hipSuccess != hipEventRecord(pev[slot * (NK + 1) + k], s) && !fail) fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
+        };
         if (part != 2) {
             mark(TFQMRGPU_PROF_DEC35);            (void)vec_launch(VEC_DEC35, d, 0, 0, s);
             mark(TFQMRGPU_PROF_XPAY_V6);          (void)vec_launch(VEC_XPAY_V6, d, 0, 0, s);
@@ -352,7 +357,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
             }
             if (prof) for (int k = 0; k < NK; ++k) {
                 float ms = 0;
-                if (hipSuccess == hipEventElapsedTime(&ms, pev[k], pev[k + 1])) { p.profMs[k] += ms; p.profLaunches[k] += 1; }
+                if (timed(k) && hipSuccess == hipEventElapsedTime(&ms, pev[k], pev[k + 1])) { p.profMs[k] += ms; p.profLaunches[k] += 1; }
             }
         }
     } else
@@ -365,6 +370,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         ++seen;
         p.boundHistory.push_back(last.max_bound2);
         if (prof) for (int k = 0; k < NK; ++k) {
+            if (!timed(k)) continue;
             bool const gated = (TFQMRGPU_PROF_PROBE == k && last.nprobes == nprobes_before); // probe not requested
             float ms = 0;
             if (hipSuccess == hipEventElapsedTime(&ms, pev[slot * (NK + 1) + k], pev[slot * (NK + 1) + k + 1])) {
@@ -381,7 +387,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         int const slot = seen % DEPTH;
         for (int k = 0; k < NK; ++k) {
             float ms = 0;
-            if (hipSuccess == hipEventElapsedTime(&ms, pev[slot * (NK + 1) + k], pev[slot * (NK + 1) + k + 1])) {
+            if (timed(k) && hipSuccess == hipEventElapsedTime(&ms, pev[slot * (NK + 1) + k], pev[slot * (NK + 1) + k + 1])) {
                 p.profGatedMs[k] += ms; p.profGatedLaunches[k] += 1;
             }
         }
@@ -764,7 +770,7 @@ int32_t tfqmrgpuExt_getBoundHistory(tfqmrgpuBsrsvPlan_t plan, double* bound2, in
 tfqmrgpuStatus_t tfqmrgpuExt_setProfiling(tfqmrgpuBsrsvPlan_t plan, int on) {
     auto p = asPlan(plan);
     if (!p) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
-    p->profiling = (0 != on);
+    p->profiling = (on < 0 || on > 2) ? 1 : on;
     return TFQMRGPU_STATUS_SUCCESS;
 }
 

@@ -101,7 +101,7 @@ struct Plan {
     double residuum_reached = 0, flops_performed = -1, flops_performed_all = 0;
     int iterations_needed = -1;
     std::vector<double> boundHistory;
-    bool profiling = false;
+    int profiling = 0;                 // 0 off, 1 every kernel class, 2 the two fused multiplies only
     int64_t profLaunches[16] = {};
     double profMs[16] = {};
     int64_t profGatedLaunches[16] = {};   // launches that found the solve stopped / no probe requested

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void k_dot35(DevPlan d) {
     double acc[2][G::VEC] = {};
     if (t < G::T) for (uint32_t w = t; w < nItems; w += G::T) {
         TFQ_ITEM_OFFSETS(G)
+        if (0xffffffffu == d.bOfX[first + blk]) continue;   // v5 is B scattered onto zeros at this point: only blocks under a B block count
         R ar[G::VEC], ai[G::VEC]; float wr[G::VEC], wi[G::VEC];
         ldv(ar, v5 + re); ldv(ai, v5 + im); ldf(wr, d.v3 + re); ldf(wi, d.v3 + im);
 #pragma unroll
@@ -530,8 +531,9 @@ static hipError_t vec_run(int op, DevPlan const& d, double tol, int maxIt, hipSt
     switch (op) {
     case VEC_SETUP: {
         size_t const S = size_t(d.nnzbX) * 2 * LM * LN * sizeof(R);
-        // x, v4..v9 are contiguous in the buffer (x first): clear them with one async memset
-        if (auto const e = hipMemsetAsync(d.x, 0, size_t((char*)d.v9 - (char*)d.x) + S, s)) return e;
+        // x, v4..v9 are contiguous in the buffer (x first): clear x, v4..v8 with one async memset (v9 is written before it is read)
+        (void)S;
+        if (auto const e = hipMemsetAsync(d.x, 0, size_t((char*)d.v9 - (char*)d.x), s)) return e;
         if (d.nnzbB) k_scatter_B<R, LM, LN><<<dim3(d.nnzbB), blk, 0, s>>>(d);
         k_init_col<R, LM, LN><<<cols, blk, 0, s>>>(d, tol, maxIt);
         k_dot35<R, LM, LN><<<grid, blk, 0, s>>>(d);
