@@ -10,7 +10,7 @@ echo "## config 2 golden instance through the reference-style driver (bench_tfqm
 python -m tfqmrgpu_amd.bench_tfqmrgpu tfQMR tests/golden/fd_16x16_small.xml z 3 2000 2>&1 | grep -v amdgpu.ids | tail -4
 for wl in stencil3d_32x32_c stencil2d_8x8_z; do
   echo "## bench.py --workload $wl"
-  python bench.py --workload $wl --steps 3 --warmup 1 2>/dev/null | tail -1
+  python bench.py --workload $wl --steps 20 --warmup 10 2>gpurun_out/configs_$wl.err | tail -1
 done
 echo "## config 4, the shard of one GPU: bench.py --workload st:16:16:z:128:128:32 (32 of the 256 block columns)"
-python bench.py --workload st:16:16:z:128:128:32 --steps 2 --warmup 1 --no-cpu-baseline --no-hbm-multiply 2>/dev/null | tail -1
+python bench.py --workload st:16:16:z:128:128:32 --steps 2 --warmup 1 --no-cpu-baseline --no-hbm-multiply 2>gpurun_out/configs_cfg4.err | tail -1

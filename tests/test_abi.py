@@ -268,3 +268,24 @@ def test_block_column_limit_and_stray_indices():
         s.create_plan(pr)
         v = s.plan_view()
         assert v["nCols"] == 3 and list(v["colindx"]) == [1, 2, 0] and list(v["original_bsrColIndX"]) == [-2147483600, 5, 2147483600]
+
+
+def test_block_rows_beyond_the_reference_s_int_overflow(oracle):
+    """the reference's createPlan checks `nnzbA > mb*mb` in 32-bit int (tfqmrgpu.cu:169): with 65 536 block rows the product
+    wraps to 0 and every system is refused with status 14 -- BASELINE config 5 (512 x 512 = 262 144 block rows) cannot run on
+    the reference.  This library has no such limit (documented deviation); bench.py's cpu_baseline falls
+    back from the reference's CPU library to the oracle there."""
+    import tfqmrgpu_amd as T
+    mb = 65536
+    rp = np.arange(mb + 1, dtype=np.int32)
+    idx = np.arange(mb, dtype=np.int32)
+    zero = np.zeros(mb, np.int32)
+    bp = np.minimum(rp, 1).astype(np.int32)                      # one block of B, in row 0
+    pr = T.Problem(rp, idx, np.broadcast_to(np.eye(4), (mb, 4, 4)), rp, zero, bp, [0], np.eye(4)[None], None, 1e-9)
+    with T.Solver() as s:
+        s.create_plan(pr)                                        # raises on any status but 0
+        v = s.plan_view()
+        assert v["nRows"] == mb and v["nCols"] == 1 and v["nPairs"] == mb
+    if oracle.have_ref():
+        st, h, plan = oracle.Reference().create_plan(pr)
+        assert T.decode(st)[:2] == (14, 169)

@@ -671,12 +671,13 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
         }
         if (q < q1) mma(o0);
 
-        uint64_t hq[2] = {0, 0};   // the shadow vector recomputed: one hash per pair of rows (tfq_device.hpp: shadow_quad)
-        if constexpr (HASH) { hq[0] = shadow_quad(key, uint32_t(lr), uint32_t(lc), LN); hq[1] = shadow_quad(key, uint32_t(lr + 4), uint32_t(lc), LN); }
         uint32_t bq = 0xffffffffu;
         if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            // the shadow vector recomputed: one hash for this pair of rows (tfq_device.hpp: shadow_quad).  Drawn here, inside the loop:
+            // both hashes in front of it cost spmm_v4_dot 2 % (0.626 against 0.614 ms on P2, profiles/r02_ab_hash.txt)
+            uint64_t const hqh = HASH ? shadow_quad(key, uint32_t(lr + 4 * h), uint32_t(lc), LN) : 0;
             d2v yr, yi, nr, ni;
             d2v br = d2v{0, 0}, bi = d2v{0, 0};
             if constexpr (EPI == EPI_RESIDUAL) if (bq != 0xffffffffu) {
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
                 }
                 if constexpr (UPD) {
                     double w0, w1;      // the logical elements (rows 2 (lr + 4 h) + e, column lc) are one quad of the shadow vector's hash
-                    if constexpr (HASH) { w0 = shadow_pick(hq[h], e, 0); w1 = shadow_pick(hq[h], e, 1); }
+                    if constexpr (HASH) { w0 = shadow_pick(hqh, e, 0); w1 = shadow_pick(hqh, e, 1); }
                     else { w0 = wr[h][e]; w1 = wi[h][e]; }
                     double const dr = nr[e], di = ni[e];
                     part[0] = __builtin_fma(-di, w1, __builtin_fma(dr, w0, part[0]));
@@ -1266,7 +1267,9 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
     }
     if constexpr (LM % 16 == 0 && LN % 16 == 0) {
         // epilogue operands prefetched under the MFMAs where the registers allow it (one 16-column tile in double, two in float)
-        constexpr bool pre = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) && ((LN / 16) * sizeof(R) <= 8);
+        // (not for 32 x 32 float: the prefetched operands take the fused kernels from 168 / 132 to 224 / 198 VGPRs = two waves per SIMD
+        //  instead of three; measured on config 3: 0.2998 / 0.2930 ms with, 0.2947 / 0.2887 ms without)
+        constexpr bool pre = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) && ((LN / 16) * sizeof(R) <= 8) && !(sizeof(R) == 4 && LM == 32 && LN == 32);
         static int const use_pre = [] { auto v = std::getenv("TFQMRGPU_EPI_PREFETCH"); return v ? std::atoi(v) : 1; }();
         // three real products per complex one where the matrix pipe bounds the kernel and the precision has room:
         // double, every shape but 16 x 16 (whose multiply is bound by the operand stream from beyond the L2: 0.486 ms on
