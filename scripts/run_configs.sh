@@ -14,3 +14,5 @@ for wl in stencil3d_32x32_c stencil2d_8x8_z; do
 done
 echo "## config 4, the shard of one GPU: bench.py --workload st:16:16:z:128:128:32 (32 of the 256 block columns)"
 python bench.py --workload st:16:16:z:128:128:32 --steps 2 --warmup 1 --no-cpu-baseline --no-hbm-multiply 2>gpurun_out/configs_cfg4.err | tail -1
+echo "## bench.py --workload st:16:16:c:96:96:16 (16x16 complex<float>, the default shape and precision of the reference's bench multi)"
+python bench.py --workload st:16:16:c:96:96:16 --steps 20 --warmup 10 --no-cpu-baseline --no-hbm-multiply 2>gpurun_out/configs_c16.err | tail -1
