@@ -182,3 +182,17 @@ def test_work_vectors_after_k_iterations_match_the_oracle(oracle, name, prec, bo
         assert scale > 0, w
         worst[w] = np.abs(got[w] - want).max() / scale
     assert max(worst.values()) <= bounds[k], worst
+
+
+def test_work_vector_getter_refuses_what_it_cannot_give():
+    pr = CASES["fd_16x16_2d"]()
+    with T.Solver() as s:
+        s.create_plan(pr)
+        out = np.zeros((pr.nnzbX, 2, pr.LM, pr.LN))
+        st = T.lib.tfqmrgpuExt_getWorkVector(s.handle, s.plan, 4, T._ptr(out))
+        assert T.decode(st)[0] == 7                                   # no buffer registered yet: TFQMRGPU_POINTER_INVALID
+        s.set_buffer(nbytes=s.buffer_size(pr.LM, pr.LN, "z"))
+        for which in (0, 2, 3, 10, -1):                                # v2 (= B) and v3 (float) are not X-shaped work vectors of this getter
+            st = T.lib.tfqmrgpuExt_getWorkVector(s.handle, s.plan, which, T._ptr(out))
+            assert T.decode(st)[0] == 18, which                        # TFQMRGPU_VARIABLENAME_UNKNOWN
+        assert T.lib.tfqmrgpuExt_getWorkVector(s.handle, s.plan, 4, None) % 1000 == 7
