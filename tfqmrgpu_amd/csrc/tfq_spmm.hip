@@ -866,6 +866,148 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 32 x 32 complex<float> (BASELINE config 3) on the quad-interleaved element order: k_spmm_ilv16f's access pattern with 2 x 2 MFMA
+// tiles per wave.  A slice is one group of four k quads (m = 0 | 1: quads lr + 4 m, 16 k values): 4 + 4 wave-wide 1-KiB loads feed
+// 64 MFMAs (k_spmm_mfma<float, 32, 32>: 16 loads of 512 bytes), and every accumulator tile is one 16-byte piece of each epilogue
+// vector (8-byte pieces there).  The ablations of profiles/r02_ab_config3.txt are why: that kernel gains time with every operand load
+// instruction that is removed.  No epilogue-operand prefetch (the registers of four tiles: three waves per SIMD matter more), v3 is read.
+template <int EPI>
+__global__ __launch_bounds__(256, 3) void k_spmm_ilv32f(SpmmArgs a) {   // three waves per SIMD: 168 VGPRs at most
+    if (gate_closed(a)) return;
+    using R = float;
+    constexpr int LN = 32, P = 1024, NPL = EpiPlanes<EPI>::N;
+    constexpr bool UPD = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
+    int const lane = threadIdx.x & 63;
+    int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int const lr = lane >> 4, lc = lane & 15;
+    using CU32 = __attribute__((address_space(4))) uint32_t const*;
+    CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
+    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    uint32_t const first = a.chunkFirst[chunk], last = a.chunkFirst[chunk + 1], col = a.chunkCol[chunk];
+    R sr[2] = {0, 0}, si[2] = {0, 0};
+    if constexpr (UPD) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            sr[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + lc + 16 * nt];
+            si[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + lc + 16 * nt];
+        }
+    }
+    double part[NPL > 0 ? NPL : 1][2] = {};
+    __shared__ double s[4][NPL > 0 ? NPL : 1][LN];
+
+    // 16 bytes of a plane: quad g (rows | k values 4 g .. 4 g + 3) of column (or A row) c:  ((g * 32 + c) * 4)
+    auto piece = [](int g, int c) { return (g * 32 + c) * 4; };
+    struct Ops { f4v ar[2], ai[2], xr[2], xi[2]; };              // [row tile | column tile]
+    auto fetch = [&](Ops& o, uint32_t q, int m) __attribute__((always_inline)) {
+        R const* Ab = (R const*)a.A + size_t(pairs[2 * size_t(q)]) * 2 * P;
+        R const* Xb = (R const*)a.X + size_t(pairs[2 * size_t(q) + 1]) * 2 * P;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            int const at = piece(lr + 4 * m, lc + 16 * t);
+            o.ar[t] = *(f4v const*)(Ab + at); o.ai[t] = *(f4v const*)(Ab + P + at);
+            o.xr[t] = *(f4v const*)(Xb + at); o.xi[t] = *(f4v const*)(Xb + P + at);
+        }
+    };
+    for (uint32_t u = wave; u < last - first; u += 4) {
+        uint32_t const y = first + u;
+        f4 cre[2][2], cim[2][2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) { cre[mt][nt] = f4{0, 0, 0, 0}; cim[mt][nt] = f4{0, 0, 0, 0}; }
+        auto mma = [&](Ops const& o) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)                           // MFMA step e contracts k = 4 (lr + 4 m) + e
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    R const nai = -o.ai[mt][e];
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        cre[mt][nt] = Acc<R>::mma(o.ar[mt][e], o.xr[nt][e], cre[mt][nt]);
+                        cim[mt][nt] = Acc<R>::mma(o.ar[mt][e], o.xi[nt][e], cim[mt][nt]);
+                        cre[mt][nt] = Acc<R>::mma(nai, o.xi[nt][e], cre[mt][nt]);
+                        cim[mt][nt] = Acc<R>::mma(o.ai[mt][e], o.xr[nt][e], cim[mt][nt]);
+                    }
+                }
+        };
+        uint32_t const q0 = starts[y], q1 = starts[y + 1];
+        Ops o0, o1;                                               // the two slices of a block product
+        if (q0 < q1) { fetch(o0, q0, 0); fetch(o1, q0, 1); }
+        for (uint32_t q = q0; q < q1; ++q) {
+            mma(o0);
+            if (q + 1 < q1) fetch(o0, q + 1, 0);
+            mma(o1);
+            if (q + 1 < q1) fetch(o1, q + 1, 1);
+        }
+
+        uint32_t bq = 0xffffffffu;
+        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                // accumulator registers 0 .. 3 of tile (mt, nt): rows 16 mt + 4 lr .. + 3 of column 16 nt + lc = one 16-byte piece
+                size_t const yoff = size_t(y) * 2 * P + piece(4 * mt + lr, 16 * nt + lc);
+                f4v ur, ui, vr, vi, wr, wi;
+                if constexpr (UPD) {
+                    ur = __builtin_nontemporal_load((f4v const*)((R const*)a.e0 + yoff)); ui = __builtin_nontemporal_load((f4v const*)((R const*)a.e0 + yoff + P));
+                    if constexpr (EPI == EPI_XPAY_DOT) { vr = __builtin_nontemporal_load((f4v const*)((R const*)a.e1 + yoff)); vi = __builtin_nontemporal_load((f4v const*)((R const*)a.e1 + yoff + P)); }
+                    wr = __builtin_nontemporal_load((f4v const*)(a.v3 + yoff)); wi = __builtin_nontemporal_load((f4v const*)(a.v3 + yoff + P));
+                }
+                f4v br = f4v{0, 0, 0, 0}, bi = f4v{0, 0, 0, 0};
+                if constexpr (EPI == EPI_RESIDUAL) if (bq != 0xffffffffu) {
+                    R const* b = (R const*)a.B + size_t(bq) * 2 * P + piece(4 * mt + lr, 16 * nt + lc);
+                    br = *(f4v const*)b; bi = *(f4v const*)(b + P);
+                }
+                f4v yr, yi, nr, ni;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    yr[e] = cre[mt][nt][e]; yi[e] = cim[mt][nt][e];
+                    if constexpr (EPI == EPI_XPAY_DOT) {         // v9 := A v6; v4 := v8 + beta v4; v4 := v9 + beta v4 (tfqmrgpu_core.hxx:196-202)
+                        R const tr = __builtin_fmaf(-si[nt], ui[e], __builtin_fmaf(sr[nt], ur[e], vr[e]));
+                        R const ti = __builtin_fmaf(sr[nt], ui[e], __builtin_fmaf(si[nt], ur[e], vi[e]));
+                        nr[e] = __builtin_fmaf(-si[nt], ti, __builtin_fmaf(sr[nt], tr, yr[e]));
+                        ni[e] = __builtin_fmaf(sr[nt], ti, __builtin_fmaf(si[nt], tr, yi[e]));
+                    } else if constexpr (EPI == EPI_AXPY_NRM_DOT) { // v8 := A v6; v5 := alfa v8 + v5 (tfqmrgpu_core.hxx:224-228)
+                        nr[e] = __builtin_fmaf(-si[nt], yi[e], __builtin_fmaf(sr[nt], yr[e], ur[e]));
+                        ni[e] = __builtin_fmaf(sr[nt], yi[e], __builtin_fmaf(si[nt], yr[e], ui[e]));
+                    }
+                    if constexpr (UPD) {
+                        double const w0 = wr[e], w1 = wi[e], dr = nr[e], di = ni[e];
+                        part[0][nt] = __builtin_fma(-di, w1, __builtin_fma(dr, w0, part[0][nt]));
+                        part[1][nt] = __builtin_fma(di, w0, __builtin_fma(dr, w1, part[1][nt]));
+                        if constexpr (EPI == EPI_AXPY_NRM_DOT) part[2][nt] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[2][nt]));
+                    } else if constexpr (EPI == EPI_RESIDUAL) {     // |A x - b|^2, nothing stored (tfqmrgpu_core.hxx:265-269)
+                        R const rr = yr[e] + R(-1) * br[e], ri = yi[e] + R(-1) * bi[e];
+                        double const dr = rr, di = ri;
+                        part[0][nt] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[0][nt]));
+                    }
+                }
+                if constexpr (EPI != EPI_RESIDUAL) { __builtin_nontemporal_store(yr, (f4v*)((R*)a.Y + yoff)); __builtin_nontemporal_store(yi, (f4v*)((R*)a.Y + yoff + P)); }
+                if constexpr (UPD) { __builtin_nontemporal_store(nr, (f4v*)((R*)a.e0 + yoff)); __builtin_nontemporal_store(ni, (f4v*)((R*)a.e0 + yoff + P)); }
+            }
+    }
+    if constexpr (NPL > 0) {
+        // rows live on lane / 16 (and registers): add the four lane groups, then the four waves in order
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                double v = part[p][nt];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (lane < 16) s[wave][p][lane + 16 * nt] = v;
+            }
+        __syncthreads();
+        for (int e = threadIdx.x; e < NPL * LN; e += 256) {
+            int const p = e / LN, j = e % LN;
+            double const sum = ((s[0][p][j] + s[1][p][j]) + s[2][p][j]) + s[3][p][j];
+            write_record<EPI>(a, chunk, LN, p, j, sum);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 8 x 8 complex<double> on the row-pair-interleaved element order (BASELINE config 5: the bandwidth-bound shape).
 // A block is 1 KiB = ONE wave-wide 16-byte access: lane (lr = lane / 16, c = (lane % 16) / 8, j = lane % 8) holds the k pair lr
 // (k = 2 lr, 2 lr + 1) of plane c (Re | Im) and column j.  The matrix tile is filled like in k_spmm_mfma8:
@@ -1256,6 +1398,9 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
             else         { if (hash) k_spmm_ilv16f<EPI, canHashF, false><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16f<EPI, false, false><<<dim3(nWG), dim3(256), 0, s>>>(a); }
             return;
         }
+    }
+    if constexpr (LM == 32 && LN == 32 && sizeof(R) == 4) {
+        if (4 == a.ilv && a.chunkFirst) { k_spmm_ilv32f<EPI><<<dim3(nWG), dim3(256), 0, s>>>(a); return; }
     }
     if constexpr (LM == 8 && LN == 8 && sizeof(R) == 8) {
         if (a.ilv && a.chunkFirst) {
