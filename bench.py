@@ -316,13 +316,18 @@ def main():
             #                               contract of the reference's gemmNxNf, what its `bench_tfqmrgpu multi` times)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-            def timed(fn, reps):
-                fn()
-                e0.record(stream)
+            def timed(fn, reps, batches=3):
+                """ms per launch: `reps` launches back to back per batch, one warm-up batch, median of `batches` (events
+                around >= 20 repetitions after the warm-ups, median)"""
                 fn(reps)
-                e1.record(stream)
-                torch.cuda.synchronize()
-                return e0.elapsed_time(e1) / reps
+                ms = []
+                for _ in range(batches):
+                    e0.record(stream)
+                    fn(reps)
+                    e1.record(stream)
+                    torch.cuda.synchronize()
+                    ms.append(e0.elapsed_time(e1) / reps)
+                return sorted(ms)[len(ms) // 2]
             s.set_matrix("X", (np.random.default_rng(1).uniform(-1, 1, (pr.nnzbX, pr.LM, pr.LN)) + 0j)) if pr.nnzbX * pr.LM * pr.LN < 5e7 else None
             copy_ms = 2 * S_bytes(pr, prec) / 5.5e9 / max(1, args.multiply_reps)      # the one vector copy behind the repetitions, at ~5.5 TB/s
             mms = timed(lambda reps=1: s.apply_operator(reps), args.multiply_reps) - copy_ms
