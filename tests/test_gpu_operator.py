@@ -34,7 +34,11 @@ def _native_A(torch, pr, prec):
 
 
 CASES = [("fd_16x16_small", "z"), ("fd_16x16_small", "c"), ("julia_kat", "z"), ("stencil_8x8", "z"), ("stencil_8x32", "c"),
-         ("dense_random_rect", "z")]
+         ("dense_random_rect", "z"), ("st32x32", "c")]    # st32x32: the quad-interleaved 32 x 32 complex<float> plan (k_spmm_ilv32f)
+
+
+def _problem(name):
+    return PR.stencil_2d(6, 6, 32, 32, 2, seed=3) if name == "st32x32" else load_problem(name)
 
 
 @pytest.mark.parametrize("name,prec", CASES)
@@ -42,7 +46,7 @@ def test_operator_that_repeats_the_builtin_multiply(torch_cuda, name, prec):
     # the callback computes the same block-sparse product with tfqmrgpuExt_multiply on the caller's block order:
     # the un-fused schedule must take the same path through the iteration as the fused one
     torch = torch_cuda
-    pr = load_problem(name)
+    pr = _problem(name)
     tol = pr.tolerance if prec == "z" else 1e-4
     st0, X0, info0 = T.solve_problem(pr, prec, threshold=tol)
     with T.Solver() as s:
