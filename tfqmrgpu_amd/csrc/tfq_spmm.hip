@@ -7,7 +7,11 @@
 // complex arithmetic on split Re/Im planes, A blocks stored transposed ([k][i]), accumulation in the
 // storage precision.  Flop count nPairs*8*LM*LM*LN (tfqmrgpu_blocksparse.hxx:198).
 //
-// Four implementations:
+// Implementations -- first the four of the plans that keep groups of rows interleaved (tfq_device.hpp: ilv_offset; every operand,
+// epilogue operand and result of a lane is one 16-byte access), the hot shapes of the BASELINE configurations:
+//  * k_spmm_ilv16  : 16 x 16 complex<double>, row pairs (configs 2 and 4);   k_spmm_ilv8 : 8 x 8 complex<double>, a block = one access (config 5);
+//  * k_spmm_ilv16f : 16 x 16 complex<float>, row quads;                      k_spmm_ilv32f : 32 x 32 complex<float>, 2 x 2 tiles per wave (config 3);
+// then, on the reference's native order (every other shape, caller-owned arrays of tfqmrgpuExt_multiply, TFQMRGPU_ILV=0):
 //  * k_spmm_mfma : LM and LN multiples of 16.  One wavefront owns a 16 x LN strip of one Y block
 //    and keeps it in MFMA accumulators (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32).  The
 //    native layouts ARE the MFMA operand layouts: lane l feeds A[k0 + l/16][i0 + l%16] and
