@@ -16,3 +16,5 @@ echo "## config 4, the shard of one GPU: bench.py --workload st:16:16:z:128:128:
 python bench.py --workload st:16:16:z:128:128:32 --steps 2 --warmup 1 --no-cpu-baseline --no-hbm-multiply 2>gpurun_out/configs_cfg4.err | tail -1
 echo "## bench.py --workload st:16:16:c:96:96:16 (16x16 complex<float>, the default shape and precision of the reference's bench multi)"
 python bench.py --workload st:16:16:c:96:96:16 --steps 20 --warmup 10 --no-cpu-baseline --no-hbm-multiply 2>gpurun_out/configs_c16.err | tail -1
+echo "## config 5 at the size SURVEY 8d restates it: bench.py --workload st:8:8:z:512:512:8 (262 144 block rows, 2.1 M X blocks, S = 2.15 GB)"
+python bench.py --workload st:8:8:z:512:512:8 --steps 3 --warmup 1 --no-cpu-baseline --no-hbm-multiply 2>gpurun_out/configs_c5big.err | tail -1
