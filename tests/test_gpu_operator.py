@@ -34,7 +34,7 @@ def _native_A(torch, pr, prec):
 
 
 CASES = [("fd_16x16_small", "z"), ("fd_16x16_small", "c"), ("julia_kat", "z"), ("stencil_8x8", "z"), ("stencil_8x32", "c"),
-         ("dense_random_rect", "z"), ("st32x32", "c")]    # st32x32: the quad-interleaved 32 x 32 complex<float> plan (k_spmm_ilv32f)
+         ("dense_random_rect", "z"), ("st32x32", "c")]    # st32x32: the quad-interleaved 32 x 32 complex<float> plan (k_spmm_ilvf)
 
 
 def _problem(name):

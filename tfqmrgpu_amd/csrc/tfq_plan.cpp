@@ -236,13 +236,13 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     size_t const blockElems = size_t(2) * LM * LN;
     p.S = size_t(p.nnzbX) * blockElems * p.realBytes;
     // groups of rows interleaved (16-byte accesses for one column) where a multiply kernel is written for it: 16 x 16 and 8 x 8
-    // complex<double> (pairs), 16 x 16 and 32 x 32 complex<float> (quads).  TFQMRGPU_ILV=0 keeps the native order everywhere (A/B runs),
-    // =16: only 16 x 16 z, =2: only the double shapes, =3: all but 32 x 32 c
+    // complex<double> (pairs), 16 x 16, 16 x 32 and 32 x 32 complex<float> (quads).  TFQMRGPU_ILV=0 keeps the native order everywhere
+    // (A/B runs), =16: only 16 x 16 z, =2: only the double shapes, =3: all but the float shapes beyond 16 x 16
     static int const ilvEnv = [] { auto v = std::getenv("TFQMRGPU_ILV"); return v ? std::atoi(v) : 1; }();
     p.ilv = 0;
     if (ilvEnv && 'z' == precision && ((16 == LM && 16 == LN) || (8 == LM && 8 == LN && ilvEnv != 16))) p.ilv = 2;
     if ((1 == ilvEnv || 3 == ilvEnv) && 'c' == precision && 16 == LM && 16 == LN) p.ilv = 4;
-    if (1 == ilvEnv && 'c' == precision && 32 == LM && 32 == LN) p.ilv = 4;
+    if (1 == ilvEnv && 'c' == precision && (16 == LM || 32 == LM) && 32 == LN) p.ilv = 4;   // 16 x 32, 32 x 32 (k_spmm_ilvf)
 
     // chunks: runs of CH blocks inside one column, sized so that a chunk of one vector is 8..16 KiB and the
     // grid has a few thousand work groups when the problem is large enough

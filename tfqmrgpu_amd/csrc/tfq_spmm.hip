@@ -10,7 +10,7 @@
 // Implementations -- first the four of the plans that keep groups of rows interleaved (tfq_device.hpp: ilv_offset; every operand,
 // epilogue operand and result of a lane is one 16-byte access), the hot shapes of the BASELINE configurations:
 //  * k_spmm_ilv16  : 16 x 16 complex<double>, row pairs (configs 2 and 4);   k_spmm_ilv8 : 8 x 8 complex<double>, a block = one access (config 5);
-//  * k_spmm_ilv16f : 16 x 16 complex<float>, row quads;                      k_spmm_ilv32f : 32 x 32 complex<float>, 2 x 2 tiles per wave (config 3);
+//  * k_spmm_ilv16f : 16 x 16 complex<float>, row quads;                      k_spmm_ilvf : 16 | 32 x 32 complex<float>, row quads (32 x 32: config 3);
 // then, on the reference's native order (every other shape, caller-owned arrays of tfqmrgpuExt_multiply, TFQMRGPU_ILV=0):
 //  * k_spmm_mfma : LM and LN multiples of 16.  One wavefront owns a 16 x LN strip of one Y block
 //    and keeps it in MFMA accumulators (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32).  The
@@ -870,16 +870,22 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 32 x 32 complex<float> (BASELINE config 3) on the quad-interleaved element order: k_spmm_ilv16f's access pattern with 2 x 2 MFMA
-// tiles per wave.  A slice is one group of four k quads (m = 0 | 1: quads lr + 4 m, 16 k values): 4 + 4 wave-wide 1-KiB loads feed
-// 64 MFMAs (k_spmm_mfma<float, 32, 32>: 16 loads of 512 bytes), and every accumulator tile is one 16-byte piece of each epilogue
-// vector (8-byte pieces there).  The ablations of profiles/r02_ab_config3.txt are why: that kernel gains time with every operand load
-// instruction that is removed.  No epilogue-operand prefetch (the registers of four tiles: three waves per SIMD matter more), v3 is read.
-template <int EPI>
-__global__ __launch_bounds__(256, 3) void k_spmm_ilv32f(SpmmArgs a) {   // three waves per SIMD: 168 VGPRs at most
+// complex<float> blocks of 16 | 32 rows and 32 columns on the quad-interleaved element order (32 x 32 = BASELINE config 3; written for
+// LM, LN multiples of 16 in general, but with 64 columns it is level with (16 x 64, 32 x 64) or 10 % behind (64 x 64) k_spmm_mfma, where a
+// lane already moves 16 bytes and four tiles of epilogue operands cost a wave per SIMD -- those shapes keep the native order):
+// k_spmm_ilv16f's access pattern with MS x NT MFMA tiles per wave.  A wave owns a strip of MS * 16 rows of a Y block (MS = 2 where the
+// block has two row tiles and 32 columns, else 1: the accumulators stay within 32 VGPRs).  A slice is one group of four k quads (quads
+// lr + 4 m, 16 k values): MS + NT pairs of wave-wide 1-KiB loads feed 16 MS NT MFMAs (32 x 32: 8 loads for 64 MFMAs, against 16 loads of 512
+// bytes in k_spmm_mfma<float, 32, 32>), and every accumulator tile is one 16-byte piece of each epilogue vector (8-byte pieces there).
+// The ablations of profiles/r02_ab_config3.txt are why: that kernel gains time with every operand load instruction that is removed.
+// No epilogue-operand prefetch (the registers of the tiles: three waves per SIMD matter more), v3 is read.
+template <int LM, int LN, int EPI>
+__global__ __launch_bounds__(256, (LN <= 32 ? 3 : 2)) void k_spmm_ilvf(SpmmArgs a) {   // 32 columns: three waves per SIMD (168 VGPRs at most; 64 columns would spill)
     if (gate_closed(a)) return;
     using R = float;
-    constexpr int LN = 32, P = 1024, NPL = EpiPlanes<EPI>::N;
+    constexpr int P = LM * LN, Q = LM * LM, MT = LM / 16, NT = LN / 16, NPL = EpiPlanes<EPI>::N;
+    constexpr int MS = (MT % 2 == 0 && NT <= 2) ? 2 : 1;          // row tiles per wave
+    constexpr int MU = MT / MS;                                   // strips per Y block
     constexpr bool UPD = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
     int const lane = threadIdx.x & 63;
     int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -888,70 +894,95 @@ __global__ __launch_bounds__(256, 3) void k_spmm_ilv32f(SpmmArgs a) {   // three
     CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
     uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;
     uint32_t const first = a.chunkFirst[chunk], last = a.chunkFirst[chunk + 1], col = a.chunkCol[chunk];
-    R sr[2] = {0, 0}, si[2] = {0, 0};
+    R sr[NT], si[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { sr[nt] = 0; si[nt] = 0; }
     if constexpr (UPD) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             sr[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + lc + 16 * nt];
             si[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + lc + 16 * nt];
         }
     }
-    double part[NPL > 0 ? NPL : 1][2] = {};
+    double part[NPL > 0 ? NPL : 1][NT] = {};
     __shared__ double s[4][NPL > 0 ? NPL : 1][LN];
 
-    // 16 bytes of a plane: quad g (rows | k values 4 g .. 4 g + 3) of column (or A row) c:  ((g * 32 + c) * 4)
-    auto piece = [](int g, int c) { return (g * 32 + c) * 4; };
-    struct Ops { f4v ar[2], ai[2], xr[2], xi[2]; };              // [row tile | column tile]
-    auto fetch = [&](Ops& o, uint32_t q, int m) __attribute__((always_inline)) {
-        R const* Ab = (R const*)a.A + size_t(pairs[2 * size_t(q)]) * 2 * P;
-        R const* Xb = (R const*)a.X + size_t(pairs[2 * size_t(q) + 1]) * 2 * P;
+    // 16 bytes of a plane: quad g (rows | k values 4 g .. 4 g + 3) of column c of an X-shaped block, of row c of a (transposed) A block
+    auto pieceX = [](int g, int c) { return (g * LN + c) * 4; };
+    auto pieceA = [](int g, int c) { return (g * LM + c) * 4; };
+    struct Ops { f4v ar[MS], ai[MS], xr[NT], xi[NT]; };
+    uint32_t const nUnits = (last - first) * MU;                  // unit = strip of MS * 16 rows of one Y block
+    for (uint32_t u = wave; u < nUnits; u += 4) {
+        uint32_t const y = first + u / MU;
+        int const t0 = int(u % MU) * MS;                          // first row tile of the strip
+        auto fetch = [&](Ops& o, uint32_t q, int m) __attribute__((always_inline)) {
+            R const* Ab = (R const*)a.A + size_t(pairs[2 * size_t(q)]) * 2 * Q;
+            R const* Xb = (R const*)a.X + size_t(pairs[2 * size_t(q) + 1]) * 2 * P;
+            // tile by tile, A and X in turn: vmcnt retires in order and the first MFMAs need the first tiles of both (3 % on 32 x 32)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            int const at = piece(lr + 4 * m, lc + 16 * t);
-            o.ar[t] = *(f4v const*)(Ab + at); o.ai[t] = *(f4v const*)(Ab + P + at);
-            o.xr[t] = *(f4v const*)(Xb + at); o.xi[t] = *(f4v const*)(Xb + P + at);
-        }
-    };
-    for (uint32_t u = wave; u < last - first; u += 4) {
-        uint32_t const y = first + u;
-        f4 cre[2][2], cim[2][2];
+            for (int t = 0; t < (MS > NT ? MS : NT); ++t) {
+                if (t < MS) {
+                    int const at = pieceA(lr + 4 * m, lc + 16 * (t0 + t));
+                    o.ar[t] = *(f4v const*)(Ab + at); o.ai[t] = *(f4v const*)(Ab + Q + at);
+                }
+                if (t < NT) {
+                    int const at = pieceX(lr + 4 * m, lc + 16 * t);
+                    o.xr[t] = *(f4v const*)(Xb + at); o.xi[t] = *(f4v const*)(Xb + P + at);
+                }
+            }
+        };
+        f4 cre[MS][NT], cim[MS][NT];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) { cre[mt][nt] = f4{0, 0, 0, 0}; cim[mt][nt] = f4{0, 0, 0, 0}; }
+            for (int nt = 0; nt < NT; ++nt) { cre[ms][nt] = f4{0, 0, 0, 0}; cim[ms][nt] = f4{0, 0, 0, 0}; }
         auto mma = [&](Ops const& o) __attribute__((always_inline)) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)                           // MFMA step e contracts k = 4 (lr + 4 m) + e
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    R const nai = -o.ai[mt][e];
+                for (int ms = 0; ms < MS; ++ms) {
+                    R const nai = -o.ai[ms][e];
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        cre[mt][nt] = Acc<R>::mma(o.ar[mt][e], o.xr[nt][e], cre[mt][nt]);
-                        cim[mt][nt] = Acc<R>::mma(o.ar[mt][e], o.xi[nt][e], cim[mt][nt]);
-                        cre[mt][nt] = Acc<R>::mma(nai, o.xi[nt][e], cre[mt][nt]);
-                        cim[mt][nt] = Acc<R>::mma(o.ai[mt][e], o.xr[nt][e], cim[mt][nt]);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        cre[ms][nt] = Acc<R>::mma(o.ar[ms][e], o.xr[nt][e], cre[ms][nt]);
+                        cim[ms][nt] = Acc<R>::mma(o.ar[ms][e], o.xi[nt][e], cim[ms][nt]);
+                        cre[ms][nt] = Acc<R>::mma(nai, o.xi[nt][e], cre[ms][nt]);
+                        cim[ms][nt] = Acc<R>::mma(o.ai[ms][e], o.xr[nt][e], cim[ms][nt]);
                     }
                 }
         };
+        // the slices of the strip in one sequence: slice t = k group (t % MT) of block product q0 + t / MT; two register sets
         uint32_t const q0 = starts[y], q1 = starts[y + 1];
-        Ops o0, o1;                                               // the two slices of a block product
-        if (q0 < q1) { fetch(o0, q0, 0); fetch(o1, q0, 1); }
-        for (uint32_t q = q0; q < q1; ++q) {
-            mma(o0);
-            if (q + 1 < q1) fetch(o0, q + 1, 0);
-            mma(o1);
-            if (q + 1 < q1) fetch(o1, q + 1, 1);
+        Ops o0, o1;
+        if constexpr (2 == MT) {          // the two register sets are the two slices of a block product (2-5 % faster than the general form below)
+            if (q0 < q1) { fetch(o0, q0, 0); fetch(o1, q0, 1); }
+            for (uint32_t q = q0; q < q1; ++q) {
+                mma(o0);
+                if (q + 1 < q1) fetch(o0, q + 1, 0);
+                mma(o1);
+                if (q + 1 < q1) fetch(o1, q + 1, 1);
+            }
+        } else {
+            uint32_t const nT = (q1 - q0) * MT;
+            if (nT > 0) fetch(o0, q0, 0);
+            if (nT > 1) fetch(o1, q0 + 1 / MT, 1 % MT);          // (MT == 1: slice 1 is the next block product)
+            for (uint32_t t = 0; t < nT; t += 2) {
+                mma(o0);
+                if (t + 2 < nT) fetch(o0, q0 + (t + 2) / MT, int((t + 2) % MT));
+                if (t + 1 < nT) mma(o1);
+                if (t + 3 < nT) fetch(o1, q0 + (t + 3) / MT, int((t + 3) % MT));
+            }
         }
 
         uint32_t bq = 0xffffffffu;
         if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                // accumulator registers 0 .. 3 of tile (mt, nt): rows 16 mt + 4 lr .. + 3 of column 16 nt + lc = one 16-byte piece
-                size_t const yoff = size_t(y) * 2 * P + piece(4 * mt + lr, 16 * nt + lc);
+            for (int nt = 0; nt < NT; ++nt) {
+                // accumulator registers 0 .. 3 of tile (ms, nt): rows 16 (t0 + ms) + 4 lr .. + 3 of column 16 nt + lc = one 16-byte piece
+                int const at = pieceX(4 * (t0 + ms) + lr, 16 * nt + lc);
+                size_t const yoff = size_t(y) * 2 * P + at;
                 f4v ur, ui, vr, vi, wr, wi;
                 if constexpr (UPD) {
                     ur = __builtin_nontemporal_load((f4v const*)((R const*)a.e0 + yoff)); ui = __builtin_nontemporal_load((f4v const*)((R const*)a.e0 + yoff + P));
@@ -960,13 +991,13 @@ __global__ __launch_bounds__(256, 3) void k_spmm_ilv32f(SpmmArgs a) {   // three
                 }
                 f4v br = f4v{0, 0, 0, 0}, bi = f4v{0, 0, 0, 0};
                 if constexpr (EPI == EPI_RESIDUAL) if (bq != 0xffffffffu) {
-                    R const* b = (R const*)a.B + size_t(bq) * 2 * P + piece(4 * mt + lr, 16 * nt + lc);
+                    R const* b = (R const*)a.B + size_t(bq) * 2 * P + at;
                     br = *(f4v const*)b; bi = *(f4v const*)(b + P);
                 }
                 f4v yr, yi, nr, ni;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    yr[e] = cre[mt][nt][e]; yi[e] = cim[mt][nt][e];
+                    yr[e] = cre[ms][nt][e]; yi[e] = cim[ms][nt][e];
                     if constexpr (EPI == EPI_XPAY_DOT) {         // v9 := A v6; v4 := v8 + beta v4; v4 := v9 + beta v4 (tfqmrgpu_core.hxx:196-202)
                         R const tr = __builtin_fmaf(-si[nt], ui[e], __builtin_fmaf(sr[nt], ur[e], vr[e]));
                         R const ti = __builtin_fmaf(sr[nt], ui[e], __builtin_fmaf(si[nt], ur[e], vi[e]));
@@ -996,7 +1027,7 @@ __global__ __launch_bounds__(256, 3) void k_spmm_ilv32f(SpmmArgs a) {   // three
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < NT; ++nt) {
                 double v = part[p][nt];
                 v += __shfl_xor(v, 16);
                 v += __shfl_xor(v, 32);
@@ -1403,8 +1434,8 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
             return;
         }
     }
-    if constexpr (LM == 32 && LN == 32 && sizeof(R) == 4) {
-        if (4 == a.ilv && a.chunkFirst) { k_spmm_ilv32f<EPI><<<dim3(nWG), dim3(256), 0, s>>>(a); return; }
+    if constexpr (sizeof(R) == 4 && LM % 16 == 0 && LN == 32) {   // (64 columns: measured level with or behind k_spmm_mfma, whose lanes already move 16 bytes there)
+        if (4 == a.ilv && a.chunkFirst) { k_spmm_ilvf<LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a); return; }
     }
     if constexpr (LM == 8 && LN == 8 && sizeof(R) == 8) {
         if (a.ilv && a.chunkFirst) {
