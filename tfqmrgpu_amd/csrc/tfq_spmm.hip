@@ -652,8 +652,13 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
         };
         uint32_t const q0 = starts[y], q1 = starts[y + 1];
         Ops o0, o1;
-        if (q0 < q1) fetch(o0, q0);
-        if (q0 + 1 < q1) fetch(o1, q0 + 1);
+        // the epilogue operands of EPI_AXPY_NRM_DOT (4 loads) are requested in FRONT of the first two block products' operands, those of
+        // EPI_XPAY_DOT (8 loads) behind them: measured both ways, profiles/r02_ab_traversal.txt (vmcnt retires in order)
+        constexpr bool EPI_FIRST = (EPI == EPI_AXPY_NRM_DOT);
+        if constexpr (!EPI_FIRST) {
+            if (q0 < q1) fetch(o0, q0);
+            if (q0 + 1 < q1) fetch(o1, q0 + 1);
+        }
         // this lane's elements of the Y block: rows (2 lr, 2 lr + 1) and (2 lr + 8, 2 lr + 9) of column lc
         int const eb[2] = { (lr * 16 + lc) * 2, ((lr + 4) * 16 + lc) * 2 };
         size_t const yoff = size_t(y) * 2 * P;
@@ -665,6 +670,10 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
                 if constexpr (EPI == EPI_XPAY_DOT) { vr[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff + eb[h])); vi[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff + eb[h] + P)); }
                 if constexpr (!HASH) { wr[h] = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff + eb[h])); wi[h] = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff + eb[h] + P)); }
             }
+        }
+        if constexpr (EPI_FIRST) {
+            if (q0 < q1) fetch(o0, q0);
+            if (q0 + 1 < q1) fetch(o1, q0 + 1);
         }
         uint32_t q = q0;
         for (; q + 2 <= q1; q += 2) {
@@ -796,14 +805,21 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
         };
         uint32_t const q0 = starts[y], q1 = starts[y + 1];
         Ops o0, o1;
-        if (q0 < q1) fetch(o0, q0);
-        if (q0 + 1 < q1) fetch(o1, q0 + 1);
+        constexpr bool EPI_FIRST = true;   // epilogue operands requested in front of the first products' operands: -1 % (profiles/r02_ab_traversal.txt)
+        if constexpr (!EPI_FIRST) {
+            if (q0 < q1) fetch(o0, q0);
+            if (q0 + 1 < q1) fetch(o1, q0 + 1);
+        }
         size_t const yoff = size_t(y) * 2 * P + mine;          // rows 4 lr .. 4 lr + 3 of column lc
         f4v ur, ui, vr, vi, wr, wi;
         if constexpr (UPD) {
             ur = __builtin_nontemporal_load((f4v const*)((R const*)a.e0 + yoff)); ui = __builtin_nontemporal_load((f4v const*)((R const*)a.e0 + yoff + P));
             if constexpr (EPI == EPI_XPAY_DOT) { vr = __builtin_nontemporal_load((f4v const*)((R const*)a.e1 + yoff)); vi = __builtin_nontemporal_load((f4v const*)((R const*)a.e1 + yoff + P)); }
             if constexpr (!HASH) { wr = __builtin_nontemporal_load((f4v const*)(a.v3 + yoff)); wi = __builtin_nontemporal_load((f4v const*)(a.v3 + yoff + P)); }
+        }
+        if constexpr (EPI_FIRST) {
+            if (q0 < q1) fetch(o0, q0);
+            if (q0 + 1 < q1) fetch(o1, q0 + 1);
         }
         uint32_t q = q0;
         for (; q + 2 <= q1; q += 2) {
@@ -1089,14 +1105,21 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8(SpmmArgs a) {
         uint32_t const q0 = starts[y], nq = starts[y + 1] - q0;
         constexpr int DEPTH = 4;
         Ops o[DEPTH];
+        constexpr bool EPI_FIRST = true;   // epilogue operands requested in front of the first products' operands: -1 % (profiles/r02_ab_traversal.txt)
+        if constexpr (!EPI_FIRST) {
 #pragma unroll
-        for (int dd = 0; dd < DEPTH; ++dd) if (uint32_t(dd) < nq) fetch(o[dd], q0 + dd);
+            for (int dd = 0; dd < DEPTH; ++dd) if (uint32_t(dd) < nq) fetch(o[dd], q0 + dd);
+        }
         size_t const yoff = size_t(y) * 2 * P + mine;
         d2v uM = d2v{0, 0}, vM = d2v{0, 0}; f2v wM = f2v{0, 0};
         if constexpr (UPD) {                       // the epilogue operands travel while the products are computed
             uM = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff));
             if constexpr (EPI == EPI_XPAY_DOT) vM = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff));
             if constexpr (!HASH) wM = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff));
+        }
+        if constexpr (EPI_FIRST) {
+#pragma unroll
+            for (int dd = 0; dd < DEPTH; ++dd) if (uint32_t(dd) < nq) fetch(o[dd], q0 + dd);
         }
         for (uint32_t base = 0; base < nq; base += DEPTH) {
 #pragma unroll
