@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Soak run: N solves of one workload on one plan; every solve must give the same iteration count, residual and solution bits
+(the kernels have no atomics and fixed reduction orders).  usage: python scripts/soak.py [workload] [N]"""
+import os, sys, hashlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import tfqmrgpu_amd as T
+from bench import build_problem
+
+name = sys.argv[1] if len(sys.argv) > 1 else "fd2d_16x16_z"
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+pr, prec, desc = build_problem(name, 0)
+s = T.Solver()
+s.create_plan(pr)
+s.set_buffer(nbytes=s.buffer_size(pr.LM, pr.LN, prec))
+s.set_matrix("A", pr.A); s.set_matrix("B", pr.B)
+seen = {}
+for i in range(N):
+    st = s.solve(pr.tolerance, 2000)
+    info = s.get_info()
+    key = (st, info["iterations"], info["residual"])
+    if i % 10 == 0 or key not in seen:
+        X = s.get_matrix()
+        key = key + (hashlib.md5(np.ascontiguousarray(X).tobytes()).hexdigest(),)
+    seen.setdefault(key[:3], []).append(i)
+    if i % 20 == 0:
+        print(i, key, flush=True)
+print("%s: %d solves, distinct (status, iterations, residual): %d" % (name, N, len(seen)))
+assert len(seen) == 1, seen
