@@ -48,7 +48,8 @@ def test_device_shadow_vector_is_the_documented_hash(name):
 # Tolerances = 2 x the deviation observed on MI355X (tests/parity_report.py -> profiles/r02_parity_report.txt) between
 # the HIP path and the oracle fed with the same vector: (whole bound history, its first half, final residual), relative.
 # How far rounding differences are amplified depends on the shadow vector; each entry is the larger of the values seen
-# with the two hash definitions this library has had (one hash per real until mid round 2 | one per four reals).
+# with the arithmetic variants this library has had (one hash per real until mid round 2 | one per four reals; compiler-contracted |
+# explicit fused multiply-adds in the epilogues and vector kernels).
 # Everything that ends at the threshold agrees to about 1e-6 (a residual of 1e-10 |b| is itself only known to ~1e-6: eps |A||x| / |r|);
 # the 3-D Poisson system at energy 0 (fd_8x8_3d) sheds 8 digits per iteration at the end, there the first half of the
 # history is what can be compared tightly.
@@ -61,7 +62,7 @@ Z_TOL = {
     "st16x16": (2e-10, 2e-12, 3e-6),          # 5.2e-11 / 9.7e-13 / 1.1e-6
     "st16x16_ragged": (1e-11, 1e-12, 1e-7),   # 1.8e-12 / 1.2e-13 / 3.8e-8
     "st16x16_onecol": (2e-11, 1e-12, 1e-7),   # 9.4e-12 / 2.3e-13 / 2.3e-8
-    "st32x32": (2e-11, 1e-12, 1e-7),          # 7.3e-12 / 2.2e-14 / 3.4e-9
+    "st32x32": (2e-11, 1e-12, 1e-6),          # 7.3e-12 / 5.6e-14 / 4.5e-7
     "fd_8x8_3d": (1.2, 2e-8, 0.55),           # 5.7e-1 / 6.6e-9 / 2.6e-1
     "fd_4x4_2d": (8e-6, 2e-9, 1.2e-5),        # 3.7e-6 / 6.2e-10 / 6.0e-6
 }
@@ -198,3 +199,40 @@ def test_work_vector_getter_refuses_what_it_cannot_give():
             st = T.lib.tfqmrgpuExt_getWorkVector(s.handle, s.plan, which, T._ptr(out))
             assert T.decode(st)[0] == 18, which                        # TFQMRGPU_VARIABLENAME_UNKNOWN
         assert T.lib.tfqmrgpuExt_getWorkVector(s.handle, s.plan, 4, None) % 1000 == 7
+
+
+# ---- a solve does not depend on what the work buffer held before -----------------------------------------------------------
+# The first iteration treats v4, v6, v7, v8 and x as the zeros they are by definition (tfqmrgpu_core.hxx:125,147-151) without
+# reading them, and the start of a solve clears only v5 (DevPlan::first): a buffer full of NaN bit patterns must give the very
+# bits of a buffer full of zeros -- for every multiply kernel family (interleaved, MFMA tiles, 8-row tiles, 4-row, operator path).
+POISON_CASES = [("fd_16x16_2d", "z"), ("fd_16x16_2d", "c"), ("stencil_8x8", "z"), ("st32x32", "c"), ("st32x32", "z"), ("stencil_8x32", "c"),
+                ("fd_4x4_2d", "z"), ("st16x16_onecol", "z")]
+
+
+@pytest.mark.parametrize("name,prec", POISON_CASES)
+def test_solve_does_not_depend_on_the_previous_buffer_content(name, prec):
+    import torch
+    pr = CASES[name]()
+    tol = pr.tolerance if prec == "z" else 1e-4
+    out = {}
+    for fill in (0x00, 0xFF):                                   # 0xFF bytes: NaN in float and double
+        with T.Solver() as s:
+            s.create_plan(pr)
+            nbytes = s.buffer_size(pr.LM, pr.LN, prec)
+            buf = torch.full((nbytes,), fill, dtype=torch.uint8, device="cuda")
+            s.set_buffer(device_ptr=buf.data_ptr())
+            s.set_matrix("A", pr.A)
+            s.set_matrix("B", pr.B)
+            st = s.solve(tol, 300)
+            info = s.get_info()
+            X = s.get_matrix()
+            st1 = s.solve(tol, 1)                               # and a solve of one iteration on the used buffer
+            X1 = s.get_matrix()
+            st0 = s.solve(tol, 0)                               # no iteration at all: X is the initial guess, zero
+            X0 = s.get_matrix()
+        out[fill] = (st, info["iterations"], info["residual"], X, st1, X1)
+        assert st0 == 9 and not X0.any()
+        assert np.isfinite(X).all() and np.isfinite(X1).all()
+    a, b = out[0x00], out[0xFF]
+    assert a[:3] == b[:3] and a[4] == b[4]
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[5], b[5])

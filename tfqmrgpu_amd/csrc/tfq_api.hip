@@ -277,7 +277,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         TFQ_HIP(hipMemcpyAsync(q + up256(size_t(p.nnzbX) * 4), cu.data(), size_t(p.nnzbX) * 2, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
         TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)   // cu goes out of scope
     }
-    auto multiply = [&](int epi) {
+    auto multiply = [&](int epi, DevPlan const& d) {     // d: the plan with the first-iteration flag of the slot
         if (!userOp) { spmm_launch(epi, d, s); return; }
         char* const xu = p.opScratch; char* const yu = xu + up256(vecBytes);
         auto const i2u = (uint32_t const*)(yu + up256(vecBytes));
@@ -299,20 +299,21 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         auto const st = reduce_over_ranks(h, &d.ctl->red[3 * what], 3, s);
         if (st && !fail) fail = st;
     };
-    auto launches = [&](int slot, int part) {
+    auto launches = [&](int slot, int part, bool firstIteration) {
+        DevPlan const dSlot = [&] { DevPlan x = d; x.first = firstIteration ? 1 : 0; return x; }();
         auto mark = [&](int k) {
             if (!(k < NK && timed(k)) && !(k > 0 && timed(k - 1))) return;
             if (hipSuccess != hipEventRecord(pev[slot * (NK + 1) + k], s) && !fail) fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
         };
         if (part != 2) {
             mark(TFQMRGPU_PROF_DEC35);            (void)vec_launch(VEC_DEC35, d, 0, 0, s);
-            mark(TFQMRGPU_PROF_XPAY_V6);          (void)vec_launch(VEC_XPAY_V6, d, 0, 0, s);
-            mark(TFQMRGPU_PROF_SPMM_V4_DOT);      multiply(EPI_XPAY_DOT);
+            mark(TFQMRGPU_PROF_XPAY_V6);          (void)vec_launch(VEC_XPAY_V6, dSlot, 0, 0, s);
+            mark(TFQMRGPU_PROF_SPMM_V4_DOT);      multiply(EPI_XPAY_DOT, dSlot);
             mark(TFQMRGPU_PROF_DEC34);            (void)vec_launch(VEC_DEC34, d, 0, 0, s);
             mark(TFQMRGPU_PROF_V5_NRM);           (void)vec_launch(VEC_V5_NRM, d, 0, 0, s);
             mark(TFQMRGPU_PROF_DECT_C67);         (void)vec_launch(VEC_DECT_C67, d, 0, 0, s);
-            mark(TFQMRGPU_PROF_X_V6_V7);          (void)vec_launch(VEC_X_V6_V7, d, 0, 0, s);
-            mark(TFQMRGPU_PROF_SPMM_V5_NRM_DOT);  multiply(EPI_AXPY_NRM_DOT);
+            mark(TFQMRGPU_PROF_X_V6_V7);          (void)vec_launch(VEC_X_V6_V7, dSlot, 0, 0, s);
+            mark(TFQMRGPU_PROF_SPMM_V5_NRM_DOT);  multiply(EPI_AXPY_NRM_DOT, dSlot);
             mark(TFQMRGPU_PROF_DECT_FINAL);       (void)vec_launch(VEC_DECT_FIN, d, 0, 0, s);
             mark(TFQMRGPU_PROF_DECIDE);
             if (multi) {
@@ -324,7 +325,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         }
         if (part != 1) {
             (void)vec_launch(VEC_X_FLUSH, d, 0, 0, s);
-            multiply(EPI_RESIDUAL);
+            multiply(EPI_RESIDUAL, dSlot);
             (void)vec_launch(VEC_PROBE_COL, d, 0, 0, s);
             if (multi) {
                 launch_probe_decide(d, 1, s);
@@ -334,8 +335,8 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         }
         mark(NK);
     };
-    auto enqueue = [&](int slot, int part = 0) {
-        launches(slot, part);
+    auto enqueue = [&](int slot, int part, bool firstIteration) {
+        launches(slot, part, firstIteration);
         // a copy that did not start would be read as a stale "still running": both calls are checked
         if ((hipSuccess != hipMemcpyAsync(&ring[slot], d.ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s) ||
              hipSuccess != hipEventRecord(ev[slot], s)) && !fail) fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
@@ -350,7 +351,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         for (int it = 0; it < maxIt && !fail && 0 == last.state; ++it) {
             for (int part = 1; part <= 2 && !fail; ++part) {   // (a failing operator still completes its slot: see reduce())
                 if (2 == part && !(0 == last.state && last.probe)) break;
-                enqueue(0, part);
+                enqueue(0, part, 0 == it);
                 if (hipSuccess != hipEventSynchronize(ev[0])) { fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED); break; }
                 last = ring[0];
                 if (1 == part) p.boundHistory.push_back(last.max_bound2);
@@ -361,7 +362,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
             }
         }
     } else
-    while (enq < std::min(ahead, maxIt)) { enqueue(enq % DEPTH); ++enq; }
+    while (enq < std::min(ahead, maxIt)) { enqueue(enq % DEPTH, 0, 0 == enq); ++enq; }   // slot n runs iteration n (or nothing)
     while (seen < enq && !fail) {
         int const slot = seen % DEPTH;
         if (hipSuccess != hipEventSynchronize(ev[slot])) { fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED); break; }
@@ -379,7 +380,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
             }
         }
         if (last.state != 0) break;
-        if (enq < maxIt) { enqueue(enq % DEPTH); ++enq; }
+        if (enq < maxIt) { enqueue(enq % DEPTH, 0, false); ++enq; }
     }
     (void)hipStreamSynchronize(s);
     // iterations that were enqueued ahead and found the solve finished: their launches return at once

@@ -53,6 +53,7 @@ struct SpmmArgs {
     int32_t const* origCol; uint32_t const* rowI;   // original block column per compressed column, block row per Y block
     int ilv;                           // element order of the plan's blocks (tfq_device.hpp: ilv_offset); the plain mode is always native
     int aOnce;                         // every A block is used about once per multiply (few block columns): stream A past the caches
+    int first;                         // EPI_XPAY_DOT in the first iteration of a solve: old v4 = v8 = 0 by definition, not read (DevPlan::first)
 };
 
 // data that a kernel touches once (epilogue vectors) moves non-temporally, so that the stream does not push the A and
@@ -64,6 +65,27 @@ template <bool STREAM, typename T> __device__ inline void st_stream(T* p, T v) {
 
 template <int EPI> struct EpiPlanes { static constexpr int N = (EPI == EPI_XPAY_DOT) ? 2 : (EPI == EPI_AXPY_NRM_DOT) ? 3 : (EPI == EPI_RESIDUAL) ? 1 : 0; };
 
+// Every epilogue writes its complex updates and reductions as EXPLICIT fused multiply-adds, the same pattern in every kernel: what the
+// compiler contracts on its own changes with the code around an expression (a refactoring of the operand loads moved the last bits of
+// the 4-row shapes, amplified to 6e-6 in the bound history of a 32-iteration solve), and the instances of one kernel that read or
+// recompute the shadow vector must round alike (tests/test_gpu_hash_mode.py compares them bit by bit).
+__device__ inline double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ inline float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// v4 := v9 + s (v8 + s v4)   (u = old v4, x = v8, y = v9 = A v6; tfqmrgpu_core.hxx:196-202)
+template <typename R> __device__ inline void epi_xpay2(R& nr, R& ni, R yr, R yi, R ur, R ui, R xr, R xi, R sr, R si) {
+    R const tr = fma_(-si, ui, fma_(sr, ur, xr)), ti = fma_(sr, ui, fma_(si, ur, xi));
+    nr = fma_(-si, ti, fma_(sr, tr, yr)); ni = fma_(sr, ti, fma_(si, tr, yi));
+}
+// v5 := s v8 + v5   (u = old v5, y = v8 = A v6; tfqmrgpu_core.hxx:224-228)
+template <typename R> __device__ inline void epi_axpy(R& nr, R& ni, R yr, R yi, R ur, R ui, R sr, R si) {
+    nr = fma_(-si, yi, fma_(sr, yr, ur)); ni = fma_(sr, yi, fma_(si, yr, ui));
+}
+// pz += v3 . d (unconjugated), pd += |d|^2, in double
+__device__ inline void epi_dot(double& p0, double& p1, double dr, double di, double wr, double wi) {
+    p0 = __builtin_fma(-di, wi, __builtin_fma(dr, wr, p0)); p1 = __builtin_fma(di, wr, __builtin_fma(dr, wi, p1));
+}
+__device__ inline void epi_nrm(double& p, double dr, double di) { p = __builtin_fma(di, di, __builtin_fma(dr, dr, p)); }
+
 // per-element epilogue; off = offset of the element's real part in an X-shaped vector, P = plane size.
 // In two steps so that a kernel can request the operands (old v4|v5, v8, v3) before its block products and use
 // them behind: EpiElem::load, epilogue_apply; epilogue() is the two in a row.
@@ -72,9 +94,12 @@ struct EpiElem {
     R ur, ui, xr, xi; float wr, wi;
     __device__ inline void load(SpmmArgs const& a, size_t off, int P) {
         if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
+            wr = ld_stream<STREAM>(a.v3 + off); wi = ld_stream<STREAM>(a.v3 + off + P);
+        }
+        if constexpr (EPI == EPI_XPAY_DOT) if (a.first) { ur = 0; ui = 0; xr = 0; xi = 0; return; }
+        if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
             R const* u = (R const*)a.e0;
             ur = ld_stream<STREAM>(u + off); ui = ld_stream<STREAM>(u + off + P);
-            wr = ld_stream<STREAM>(a.v3 + off); wi = ld_stream<STREAM>(a.v3 + off + P);
         }
         if constexpr (EPI == EPI_XPAY_DOT) {
             R const* v8 = (R const*)a.e1;
@@ -94,30 +119,26 @@ __device__ inline void epilogue_apply(SpmmArgs const& a, size_t off, int P, R yr
         // (tfqmrgpu_core.hxx:196-202)
         st_stream<STREAM>((R*)a.Y + off, yr); st_stream<STREAM>((R*)a.Y + off + P, yi);
         R* v4 = (R*)a.e0;
-        R const tr = o.xr + sr * o.ur - si * o.ui, ti = o.xi + si * o.ur + sr * o.ui;
-        R const ur = yr + sr * tr - si * ti, ui = yi + si * tr + sr * ti;
+        R ur, ui;
+        epi_xpay2(ur, ui, yr, yi, o.ur, o.ui, o.xr, o.xi, sr, si);
         st_stream<STREAM>(v4 + off, ur); st_stream<STREAM>(v4 + off + P, ui);
-        double const wr = o.wr, wi = o.wi, dr = ur, di = ui;
-        acc[0] += dr * wr - di * wi;
-        acc[1] += dr * wi + di * wr;
+        epi_dot(acc[0], acc[1], ur, ui, o.wr, o.wi);
     } else if constexpr (EPI == EPI_AXPY_NRM_DOT) {
         // v8 := A v6; v5 := alfa v8 + v5; pd += |v5|^2; pz += v3 . v5  (tfqmrgpu_core.hxx:224-228,189)
         st_stream<STREAM>((R*)a.Y + off, yr); st_stream<STREAM>((R*)a.Y + off + P, yi);
         R* v5 = (R*)a.e0;
-        R const nr = sr * yr - si * yi + o.ur, ni = si * yr + sr * yi + o.ui;
+        R nr, ni;
+        epi_axpy(nr, ni, yr, yi, o.ur, o.ui, sr, si);
         st_stream<STREAM>(v5 + off, nr); st_stream<STREAM>(v5 + off + P, ni);
-        double const wr = o.wr, wi = o.wi, dr = nr, di = ni;
-        acc[0] += dr * wr - di * wi;
-        acc[1] += dr * wi + di * wr;
-        acc[2] += dr * dr + di * di;
+        epi_dot(acc[0], acc[1], nr, ni, o.wr, o.wi);
+        epi_nrm(acc[2], nr, ni);
     } else { // EPI_RESIDUAL: |A x - b|^2, nothing stored (tfqmrgpu_core.hxx:265-269)
         R rr = yr, ri = yi;
         if (bq != 0xffffffffu) {
             R const* b = (R const*)a.B + size_t(bq) * 2 * P;
             rr += R(-1) * b[eoff]; ri += R(-1) * b[eoff + P];
         }
-        double const dr = rr, di = ri;
-        acc[0] += dr * dr + di * di;
+        epi_nrm(acc[0], rr, ri);
     }
 }
 
@@ -190,8 +211,8 @@ __global__ __launch_bounds__(256) void k_spmm_direct(SpmmArgs a) {
                 for (int k = 0; k < LM; ++k) {
                     R const ar = Ab[k * LM + i], ai = Ab[LM * LM + k * LM + i];
                     R const xr = Xb[k * LN + j], xi = Xb[P + k * LN + j];
-                    cr += ar * xr - ai * xi;
-                    ci += ar * xi + ai * xr;
+                    cr = fma_(-ai, xi, fma_(ar, xr, cr));
+                    ci = fma_(ai, xr, fma_(ar, xi, ci));
                 }
                 yr[n] += cr; yi[n] += ci;
             }
@@ -373,8 +394,15 @@ struct EpiOps {
     float wr[NT], wi[NT];
     __device__ inline void load(SpmmArgs const& a, size_t off, int P) {
         if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
-            vload_stream<STREAM, R, NT>(ur, (R const*)a.e0 + off); vload_stream<STREAM, R, NT>(ui, (R const*)a.e0 + off + P);
             if constexpr (!HASH) { vload_stream<STREAM, float, NT>(wr, a.v3 + off); vload_stream<STREAM, float, NT>(wi, a.v3 + off + P); }   // HASH: recomputed in epilogue_row
+        }
+        if constexpr (EPI == EPI_XPAY_DOT) if (a.first) {          // first iteration of a solve: old v4 = v8 = 0, not read
+#pragma unroll
+            for (int n = 0; n < NT; ++n) { ur[n] = 0; ui[n] = 0; xr[n] = 0; xi[n] = 0; }
+            return;
+        }
+        if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
+            vload_stream<STREAM, R, NT>(ur, (R const*)a.e0 + off); vload_stream<STREAM, R, NT>(ui, (R const*)a.e0 + off + P);
         }
         if constexpr (EPI == EPI_XPAY_DOT) { vload_stream<STREAM, R, NT>(xr, (R const*)a.e1 + off); vload_stream<STREAM, R, NT>(xi, (R const*)a.e1 + off + P); }
     }
@@ -393,19 +421,13 @@ __device__ inline void epilogue_row(SpmmArgs const& a, size_t off, int P, R cons
 #pragma unroll
         for (int n = 0; n < VW; ++n) {
             R const cr = sr[n0 + n], ci = si[n0 + n];
-            if constexpr (EPI == EPI_XPAY_DOT) {
-                R const tr = o.xr[n] + cr * o.ur[n] - ci * o.ui[n], ti = o.xi[n] + ci * o.ur[n] + cr * o.ui[n];
-                nr[n] = yr[n] + cr * tr - ci * ti; ni[n] = yi[n] + ci * tr + cr * ti;
-            } else {
-                nr[n] = cr * yr[n] - ci * yi[n] + o.ur[n]; ni[n] = ci * yr[n] + cr * yi[n] + o.ui[n];
-            }
+            if constexpr (EPI == EPI_XPAY_DOT) epi_xpay2(nr[n], ni[n], yr[n], yi[n], o.ur[n], o.ui[n], o.xr[n], o.xi[n], cr, ci);
+            else epi_axpy(nr[n], ni[n], yr[n], yi[n], o.ur[n], o.ui[n], cr, ci);
             double wr, wi;   // the shadow vector: read, or recomputed from its hash (tfq_device.hpp)
             if constexpr (HASH) { uint64_t const hq = shadow_quad(key, uint32_t(eoff + n) / (2 * LN), uint32_t(eoff + n) % LN, LN); int const odd = (uint32_t(eoff + n) / LN) & 1; wr = shadow_pick(hq, odd, 0); wi = shadow_pick(hq, odd, 1); }
             else { wr = o.wr[n]; wi = o.wi[n]; }
-            double const dr = nr[n], di = ni[n];
-            part[0][n0 + n] += dr * wr - di * wi;
-            part[1][n0 + n] += dr * wi + di * wr;
-            if constexpr (EPI == EPI_AXPY_NRM_DOT) part[2][n0 + n] += dr * dr + di * di;
+            epi_dot(part[0][n0 + n], part[1][n0 + n], nr[n], ni[n], wr, wi);
+            if constexpr (EPI == EPI_AXPY_NRM_DOT) epi_nrm(part[2][n0 + n], nr[n], ni[n]);
         }
         vstore_stream<EpiOps<R, EPI, VW, HASH>::STREAM, R, VW>((R*)a.e0 + off, nr); vstore_stream<EpiOps<R, EPI, VW, HASH>::STREAM, R, VW>((R*)a.e0 + off + P, ni);
     } else if constexpr (EPI == EPI_RESIDUAL) {
@@ -417,8 +439,7 @@ __device__ inline void epilogue_row(SpmmArgs const& a, size_t off, int P, R cons
 #pragma unroll
         for (int n = 0; n < VW; ++n) {
             R const rr = yr[n] + R(-1) * br[n], ri = yi[n] + R(-1) * bi[n];
-            double const dr = rr, di = ri;
-            part[0][n0 + n] += dr * dr + di * di;
+            epi_nrm(part[0][n0 + n], rr, ri);
         }
     }
 }
@@ -666,8 +687,11 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
         if constexpr (UPD) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {   // old v4 | v5, v8, v3: touched once, non-temporal
+                if (EPI == EPI_XPAY_DOT && a.first) { ur[h] = d2v{0, 0}; ui[h] = d2v{0, 0}; vr[h] = d2v{0, 0}; vi[h] = d2v{0, 0}; }   // first iteration: old v4 = v8 = 0, not read
+                else {
                 ur[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff + eb[h])); ui[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff + eb[h] + P));
                 if constexpr (EPI == EPI_XPAY_DOT) { vr[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff + eb[h])); vi[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff + eb[h] + P)); }
+                }
                 if constexpr (!HASH) { wr[h] = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff + eb[h])); wi[h] = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff + eb[h] + P)); }
             }
         }
@@ -813,8 +837,11 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
         size_t const yoff = size_t(y) * 2 * P + mine;          // rows 4 lr .. 4 lr + 3 of column lc
         f4v ur, ui, vr, vi, wr, wi;
         if constexpr (UPD) {
+            if (EPI == EPI_XPAY_DOT && a.first) { ur = f4v{0, 0, 0, 0}; ui = ur; vr = ur; vi = ur; }   // first iteration: old v4 = v8 = 0, not read
+            else {
             ur = __builtin_nontemporal_load((f4v const*)((R const*)a.e0 + yoff)); ui = __builtin_nontemporal_load((f4v const*)((R const*)a.e0 + yoff + P));
             if constexpr (EPI == EPI_XPAY_DOT) { vr = __builtin_nontemporal_load((f4v const*)((R const*)a.e1 + yoff)); vi = __builtin_nontemporal_load((f4v const*)((R const*)a.e1 + yoff + P)); }
+            }
             if constexpr (!HASH) { wr = __builtin_nontemporal_load((f4v const*)(a.v3 + yoff)); wi = __builtin_nontemporal_load((f4v const*)(a.v3 + yoff + P)); }
         }
         if constexpr (EPI_FIRST) {
@@ -1001,8 +1028,11 @@ __global__ __launch_bounds__(256, (LN <= 32 ? 3 : 2)) void k_spmm_ilvf(SpmmArgs 
                 size_t const yoff = size_t(y) * 2 * P + at;
                 f4v ur, ui, vr, vi, wr, wi;
                 if constexpr (UPD) {
+                    if (EPI == EPI_XPAY_DOT && a.first) { ur = f4v{0, 0, 0, 0}; ui = ur; vr = ur; vi = ur; }   // first iteration: old v4 = v8 = 0, not read
+                    else {
                     ur = __builtin_nontemporal_load((f4v const*)((R const*)a.e0 + yoff)); ui = __builtin_nontemporal_load((f4v const*)((R const*)a.e0 + yoff + P));
                     if constexpr (EPI == EPI_XPAY_DOT) { vr = __builtin_nontemporal_load((f4v const*)((R const*)a.e1 + yoff)); vi = __builtin_nontemporal_load((f4v const*)((R const*)a.e1 + yoff + P)); }
+                    }
                     wr = __builtin_nontemporal_load((f4v const*)(a.v3 + yoff)); wi = __builtin_nontemporal_load((f4v const*)(a.v3 + yoff + P));
                 }
                 f4v br = f4v{0, 0, 0, 0}, bi = f4v{0, 0, 0, 0};
@@ -1113,8 +1143,10 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8(SpmmArgs a) {
         size_t const yoff = size_t(y) * 2 * P + mine;
         d2v uM = d2v{0, 0}, vM = d2v{0, 0}; f2v wM = f2v{0, 0};
         if constexpr (UPD) {                       // the epilogue operands travel while the products are computed
+            if (!(EPI == EPI_XPAY_DOT && a.first)) {   // (first iteration of a solve: old v4 = v8 = 0, not read)
             uM = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff));
             if constexpr (EPI == EPI_XPAY_DOT) vM = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff));
+            }
             if constexpr (!HASH) wM = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff));
         }
         if constexpr (EPI_FIRST) {
@@ -1399,8 +1431,8 @@ __global__ __launch_bounds__(256) void k_spmm_small4(SpmmArgs a) {
             for (int k = 0; k < LM; ++k) {
                 R const ar = As[g][0][k * LM + i], ai = As[g][1][k * LM + i];
                 R const xr = Xs[g][0][k * LNS + jj], xi = Xs[g][1][k * LNS + jj];
-                cr += ar * xr - ai * xi;
-                ci += ar * xi + ai * xr;
+                cr = fma_(-ai, xi, fma_(ar, xr, cr));
+                ci = fma_(ai, xr, fma_(ar, xi, ci));
             }
             yr += cr; yi += ci;
         }
@@ -1554,7 +1586,7 @@ static SpmmArgs spmm_args(int epi, DevPlan const& d) {
     a.ctl = d.ctl; a.v3 = d.v3; a.B = d.B; a.bOfX = d.bOfX; a.pz = d.pz; a.pd = d.pd;
     a.hashV3 = d.hashV3; a.origCol = d.origCol; a.rowI = d.rowI; a.ilv = d.ilv; a.aOnce = d.aOnce;
     switch (epi) {
-    case EPI_XPAY_DOT:     a.X = d.v6; a.Y = d.v9; a.e0 = d.v4; a.e1 = d.v8; a.sc = d.beta; a.gate = 1; break;
+    case EPI_XPAY_DOT:     a.X = d.v6; a.Y = d.v9; a.e0 = d.v4; a.e1 = d.v8; a.sc = d.beta; a.gate = 1; a.first = d.first; break;
     case EPI_AXPY_NRM_DOT: a.X = d.v6; a.Y = d.v8; a.e0 = d.v5; a.sc = d.alfa; a.gate = 1; break;
     case EPI_RESIDUAL:     a.X = d.x;  a.Y = nullptr; a.gate = 2; break;
     default: break;

@@ -78,16 +78,20 @@ struct Scal {
     }
 };
 
-// y := x + a*y  (reference expression order, tfqmrgpu_linalg.hxx:660-661)
+// Explicit fused multiply-adds, one fixed pattern: what the compiler contracts on its own depends on the code around the expression
+// (tfq_spmm.hip has the story), and results must not move when a kernel is refactored.
+__device__ inline double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ inline float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// y := x + a*y  (tfqmrgpu_linalg.hxx:660-661)
 template <typename R> __device__ inline void xpay(R& yr, R& yi, R xr, R xi, R ar, R ai) {
-    R const nr = xr + ar * yr - ai * yi;
-    R const ni = xi + ai * yr + ar * yi;
+    R const nr = fma_(-ai, yi, fma_(ar, yr, xr));
+    R const ni = fma_(ar, yi, fma_(ai, yr, xi));
     yr = nr; yi = ni;
 }
 // y := a*x + y  (tfqmrgpu_linalg.hxx:656-657)
 template <typename R> __device__ inline void axpy(R& yr, R& yi, R xr, R xi, R ar, R ai) {
-    R const nr = ar * xr - ai * xi + yr;
-    R const ni = ai * xr + ar * xi + yi;
+    R const nr = fma_(-ai, xi, fma_(ar, xr, yr));
+    R const ni = fma_(ar, xi, fma_(ai, xr, yi));
     yr = nr; yi = ni;
 }
 
@@ -147,8 +151,8 @@ __global__ __launch_bounds__(256) void k_dot35(DevPlan d) {
 #pragma unroll
         for (int v = 0; v < G::VEC; ++v) {
             double const xr = ar[v], xi = ai[v], yr = wr[v], yi = wi[v];
-            acc[0][v] += xr * yr - xi * yi;
-            acc[1][v] += xr * yi + xi * yr;
+            acc[0][v] = __builtin_fma(-xi, yi, __builtin_fma(xr, yr, acc[0][v]));
+            acc[1][v] = __builtin_fma(xi, yr, __builtin_fma(xr, yi, acc[1][v]));
         }
     }
     chunk_reduce<LN, G::VEC, G::T, 2>(acc, s, d.pz + size_t(chunk) * 2 * LN, t, d.ilv);
@@ -165,7 +169,11 @@ __global__ __launch_bounds__(256) void k_xpay_v6(DevPlan d) {
     for (uint32_t w = t; w < nItems; w += G::T) {
         TFQ_ITEM_OFFSETS(G)
         R xr[G::VEC], xi[G::VEC], yr[G::VEC], yi[G::VEC];
-        ldv(xr, v5 + re); ldv(xi, v5 + im); ldv(yr, v6 + re); ldv(yi, v6 + im);
+        ldv(xr, v5 + re); ldv(xi, v5 + im);
+        if (d.first) {                                   // v6 = 0 at the start of a solve: not read (same arithmetic on zeros)
+#pragma unroll
+            for (int v = 0; v < G::VEC; ++v) { yr[v] = 0; yi[v] = 0; }
+        } else { ldv(yr, v6 + re); ldv(yi, v6 + im); }
 #pragma unroll
         for (int v = 0; v < G::VEC; ++v) xpay(yr[v], yi[v], xr[v], xi[v], beta.re[v], beta.im[v]);
         stv(v6 + re, yr); stv(v6 + im, yi);
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256) void k_v5_nrm(DevPlan d) {
             for (int v = 0; v < G::VEC; ++v) {
                 axpy(br[v], bi[v], ar[v], ai[v], alfa.re[v], alfa.im[v]);
                 double const r = br[v], i = bi[v];
-                acc[0][v] += r * r + i * i;
+                acc[0][v] = __builtin_fma(i, i, __builtin_fma(r, r, acc[0][v]));
             }
             stv(v5 + re, br); stv(v5 + im, bi);
         }
@@ -218,7 +226,10 @@ __global__ __launch_bounds__(256) void k_x_v6_v7(DevPlan d) {
     for (uint32_t w = t; w < nItems; w += G::T) {
         TFQ_ITEM_OFFSETS(G)
         R sr[G::VEC], si[G::VEC], xr[G::VEC], xi[G::VEC], ar[G::VEC], ai[G::VEC], br[G::VEC], bi[G::VEC];
-        ldv(sr, v7 + re); ldv(si, v7 + im); ldv(xr, x + re); ldv(xi, x + im);
+        if (d.first) {                                   // v7 = x = 0 at the start of a solve: not read (same arithmetic on zeros)
+#pragma unroll
+            for (int v = 0; v < G::VEC; ++v) { sr[v] = 0; si[v] = 0; xr[v] = 0; xi[v] = 0; }
+        } else { ldv(sr, v7 + re); ldv(si, v7 + im); ldv(xr, x + re); ldv(xi, x + im); }
         ldv(ar, v4 + re); ldv(ai, v4 + im); ldv(br, v6 + re); ldv(bi, v6 + im);
 #pragma unroll
         for (int v = 0; v < G::VEC; ++v) {
@@ -494,7 +505,7 @@ __global__ __launch_bounds__(256) void k_init_col(DevPlan d, double tol, int max
         for (int i = g; i < LM; i += G) {
             int const e = plane_offset(d.ilv, i, j, LN);
             double const r = b[e], im = b[P + e];
-            acc += r * r + im * im;
+            acc = __builtin_fma(im, im, __builtin_fma(r, r, acc));
         }
     }
     if (g < G) s[g * LN + j] = acc;
@@ -531,9 +542,10 @@ static hipError_t vec_run(int op, DevPlan const& d, double tol, int maxIt, hipSt
     switch (op) {
     case VEC_SETUP: {
         size_t const S = size_t(d.nnzbX) * 2 * LM * LN * sizeof(R);
-        // x, v4..v9 are contiguous in the buffer (x first): clear x, v4..v8 with one async memset (v9 is written before it is read)
-        (void)S;
-        if (auto const e = hipMemsetAsync(d.x, 0, size_t((char*)d.v9 - (char*)d.x), s)) return e;
+        // only v5 is cleared (B is scattered onto it): x, v4, v6, v7, v8 are zero by definition in the first iteration and its
+        // kernels do not read them (DevPlan::first), v9 is written before it is read.  No iteration at all: x is the answer, zero.
+        if (auto const e = hipMemsetAsync(d.v5, 0, S, s)) return e;
+        if (maxIt <= 0) if (auto const e = hipMemsetAsync(d.x, 0, S, s)) return e;
         if (d.nnzbB) k_scatter_B<R, LM, LN><<<dim3(d.nnzbB), blk, 0, s>>>(d);
         k_init_col<R, LM, LN><<<cols, blk, 0, s>>>(d, tol, maxIt);
         k_dot35<R, LM, LN><<<grid, blk, 0, s>>>(d);
