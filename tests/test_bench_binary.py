@@ -57,7 +57,8 @@ def test_tfqmr_mode_extension_lines_and_one_rank_through_rccl():
     assert plain.returncode == 0, plain.stdout + plain.stderr
     assert re.search(r"# GPU iterations per second: \S+ \(9 block columns x 16 right-hand sides", plain.stdout)
     m = re.search(r"# MI355X roofline: fused multiply (spmm_v4_dot|spmm_v5_nrm_dot), (\d+) launches of (\S+) ms: (\S+) GB/s of algorithmic bytes = (\S+) of 8 TB/s HBM", plain.stdout)
-    assert m and int(m.group(2)) == int(g["solve_z_iterations"]) and 0 < float(m.group(5)) < 1
+    # (the launches of steady iterations: the first iteration of a solve skips the vectors that are zero there and is kept apart)
+    assert m and int(m.group(2)) == int(g["solve_z_iterations"]) - 1 and 0 < float(m.group(5)) < 1
     ranks = subprocess.run([EXE, "tfQMR", os.path.join(GOLD, "fd_16x16_2d.xml"), "z", "1", "2000", "--gpus", "1"],
                            capture_output=True, text=True, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert ranks.returncode == 0, ranks.stdout + ranks.stderr

@@ -586,3 +586,21 @@ def test_three_product_form_error_bound(torch_cuda, oracle):
     assert np.abs(got[:, 1] - want[:, 1]).max() <= 8 * eps * scale      # absolute: the same bound as the real part ...
     rel_im = np.abs(got[:, 1] - want[:, 1]).max() / np.abs(want[:, 1]).max()
     assert rel_im <= 8 * eps * scale / 1e-8                               # ... i.e. up to 1e8 times eps relative to Im itself
+
+
+def test_profile_keeps_the_first_iteration_apart():
+    """tfqmrgpuExt_getProfileFirst: of the launches that did work, those of the first iteration (one per class and solve)"""
+    pr = load_problem("fd_16x16_2d")
+    with T.Solver() as s:
+        s.create_plan(pr)
+        s.set_buffer(nbytes=s.buffer_size(16, 16, "z"))
+        s.set_matrix("A", pr.A)
+        s.set_matrix("B", pr.B)
+        s.set_profiling(1)
+        assert s.solve(1e-9, 2000) == 0
+        it = s.get_info()["iterations"]
+        allp, first = s.profile(), s.profile(first=True)
+        for k in ("xpay_v6", "spmm_v4_dot", "x_v6_v7", "spmm_v5_nrm_dot"):
+            assert allp[k][0] == it and first[k][0] == 1 and 0 < first[k][1] < allp[k][1], k
+        assert s.solve(1e-9, 1) == 9                       # a solve of one iteration: every working launch is a first-iteration launch
+        assert s.profile()["spmm_v4_dot"][0] == s.profile(first=True)["spmm_v4_dot"][0] == 1

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [  # include/tfqmrgpu.h
 ]
 EXT_SYMBOLS = [  # include/tfqmrgpu_ext.h
     "tfqmrgpuExt_planView", "tfqmrgpuExt_getBoundHistory", "tfqmrgpuExt_setProfiling", "tfqmrgpuExt_getProfile",
-    "tfqmrgpuExt_getProfileGated",
+    "tfqmrgpuExt_getProfileGated", "tfqmrgpuExt_getProfileFirst",
     "tfqmrgpuExt_setShadowMode",
     "tfqmrgpuExt_setShadowVector", "tfqmrgpuExt_getShadowVector", "tfqmrgpuExt_getWorkVector", "tfqmrgpuExt_multiply", "tfqmrgpuExt_applyOperator", "tfqmrgpuExt_shardColumns",
     "tfqmrgpuExt_freeShard", "tfqmrgpuExt_commUniqueId", "tfqmrgpuExt_commInit",
@@ -112,6 +112,7 @@ def load_library(path=LIB_PATH):
     lib.tfqmrgpuExt_setProfiling.argtypes = [P, I]
     lib.tfqmrgpuExt_getProfile.argtypes = [P, P, P]
     lib.tfqmrgpuExt_getProfileGated.argtypes = [P, P, P]
+    lib.tfqmrgpuExt_getProfileFirst.argtypes = [P, P, P]
     lib.tfqmrgpuExt_setShadowMode.argtypes = [P, I]
     lib.tfqmrgpuExt_setShadowVector.argtypes = [P, P, P]
     lib.tfqmrgpuExt_getShadowVector.argtypes = [P, P, P]
@@ -319,11 +320,12 @@ class Solver:
     def set_profiling(self, on=True):
         _check(lib.tfqmrgpuExt_setProfiling(self.plan, int(on)), "tfqmrgpuExt_setProfiling")
 
-    def profile(self, gated=False):
-        """{kernel class: (launches, total ms)} of the last solve; gated=True: the launches that returned at once"""
+    def profile(self, gated=False, first=False):
+        """{kernel class: (launches, total ms)} of the last solve; gated=True: the launches that returned at once;
+        first=True: of the launches that did work, those of the first iteration (which skip the operands that are zero there)"""
         n = len(self.PROFILE_CLASSES)
         cnt, ms = np.zeros(n, np.int64), np.zeros(n, np.float64)
-        fn = lib.tfqmrgpuExt_getProfileGated if gated else lib.tfqmrgpuExt_getProfile
+        fn = lib.tfqmrgpuExt_getProfileGated if gated else lib.tfqmrgpuExt_getProfileFirst if first else lib.tfqmrgpuExt_getProfile
         _check(fn(self.plan, _ptr(cnt), _ptr(ms)), "tfqmrgpuExt_getProfile")
         return {k: (int(cnt[i]), float(ms[i])) for i, k in enumerate(self.PROFILE_CLASSES)}
 

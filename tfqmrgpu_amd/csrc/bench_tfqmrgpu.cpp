@@ -423,6 +423,11 @@ int tfqmr_rank(std::string const& path, char prec, int maxiter, int rank, int nr
                     int(std::set<int32_t>(X.colInd.begin(), X.colInd.end()).size()), LN);
         int64_t launches[TFQMRGPU_PROFILE_CLASSES]; double ms[TFQMRGPU_PROFILE_CLASSES];
         CHECK_TFQ(tfqmrgpuExt_getProfile(plan, launches, ms));
+        {   // the launches of the first iteration read fewer vectors (tfqmrgpu_ext.h): the roofline line is about the steady ones
+            int64_t l1[TFQMRGPU_PROFILE_CLASSES]; double m1[TFQMRGPU_PROFILE_CLASSES];
+            CHECK_TFQ(tfqmrgpuExt_getProfileFirst(plan, l1, m1));
+            for (int c = 0; c < TFQMRGPU_PROFILE_CLASSES; ++c) if (launches[c] > l1[c]) { launches[c] -= l1[c]; ms[c] -= m1[c]; }
+        }
         tfqmrgpuPlanView_t v;
         CHECK_TFQ(tfqmrgpuExt_planView(plan, &v));
         int const k = (ms[TFQMRGPU_PROF_SPMM_V4_DOT] >= ms[TFQMRGPU_PROF_SPMM_V5_NRM_DOT]) ? TFQMRGPU_PROF_SPMM_V4_DOT : TFQMRGPU_PROF_SPMM_V5_NRM_DOT;

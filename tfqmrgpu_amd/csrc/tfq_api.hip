@@ -252,7 +252,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
     auto const timed = [prof](int k) { return 1 == prof || (2 == prof && (TFQMRGPU_PROF_SPMM_V4_DOT == k || TFQMRGPU_PROF_SPMM_V5_NRM_DOT == k)); };
     EventList pev;
     if (prof && !pev.create(size_t(DEPTH) * (NK + 1))) return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED);
-    for (int k = 0; k < NK; ++k) { p.profLaunches[k] = 0; p.profMs[k] = 0; p.profGatedLaunches[k] = 0; p.profGatedMs[k] = 0; }
+    for (int k = 0; k < NK; ++k) { p.profLaunches[k] = 0; p.profMs[k] = 0; p.profGatedLaunches[k] = 0; p.profGatedMs[k] = 0; p.profFirstLaunches[k] = 0; p.profFirstMs[k] = 0; }
 
     p.boundHistory.clear();
     p.iterations_needed = maxIt; p.flops_performed = 0;
@@ -358,7 +358,10 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
             }
             if (prof) for (int k = 0; k < NK; ++k) {
                 float ms = 0;
-                if (timed(k) && hipSuccess == hipEventElapsedTime(&ms, pev[k], pev[k + 1])) { p.profMs[k] += ms; p.profLaunches[k] += 1; }
+                if (timed(k) && hipSuccess == hipEventElapsedTime(&ms, pev[k], pev[k + 1])) {
+                    p.profMs[k] += ms; p.profLaunches[k] += 1;
+                    if (0 == it) { p.profFirstMs[k] += ms; p.profFirstLaunches[k] += 1; }
+                }
             }
         }
     } else
@@ -376,7 +379,10 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
             float ms = 0;
             if (hipSuccess == hipEventElapsedTime(&ms, pev[slot * (NK + 1) + k], pev[slot * (NK + 1) + k + 1])) {
                 if (gated) { p.profGatedMs[k] += ms; p.profGatedLaunches[k] += 1; }
-                else { p.profMs[k] += ms; p.profLaunches[k] += 1; }
+                else {
+                    p.profMs[k] += ms; p.profLaunches[k] += 1;
+                    if (1 == seen) { p.profFirstMs[k] += ms; p.profFirstLaunches[k] += 1; }   // the slot of the first iteration
+                }
             }
         }
         if (last.state != 0) break;
@@ -786,6 +792,13 @@ tfqmrgpuStatus_t tfqmrgpuExt_getProfileGated(tfqmrgpuBsrsvPlan_t plan, int64_t* 
     auto p = asPlan(plan);
     if (!p || !launches || !milliseconds) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
     for (int k = 0; k < TFQMRGPU_PROFILE_CLASSES; ++k) { launches[k] = p->profGatedLaunches[k]; milliseconds[k] = p->profGatedMs[k]; }
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+tfqmrgpuStatus_t tfqmrgpuExt_getProfileFirst(tfqmrgpuBsrsvPlan_t plan, int64_t* launches, double* milliseconds) {
+    auto p = asPlan(plan);
+    if (!p || !launches || !milliseconds) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    for (int k = 0; k < TFQMRGPU_PROFILE_CLASSES; ++k) { launches[k] = p->profFirstLaunches[k]; milliseconds[k] = p->profFirstMs[k]; }
     return TFQMRGPU_STATUS_SUCCESS;
 }
 

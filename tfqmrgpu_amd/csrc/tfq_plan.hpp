@@ -106,6 +106,8 @@ struct Plan {
     double profMs[16] = {};
     int64_t profGatedLaunches[16] = {};   // launches that found the solve stopped / no probe requested
     double profGatedMs[16] = {};
+    int64_t profFirstLaunches[16] = {};   // of profLaunches: the launches of the first iteration (they skip the operands that are zero there)
+    double profFirstMs[16] = {};
 
     size_t nPairs() const { return pairs.size() / 2; }
 };

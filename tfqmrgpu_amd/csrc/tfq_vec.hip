@@ -12,6 +12,8 @@
 //    between two scalar barriers), the second x update of an iteration rides on the next iteration;
 //  * reductions are deterministic: fixed shuffle-free LDS order inside a work group, fixed chunk
 //    order per column in the decision kernels.
+#include <type_traits>
+
 #include "tfq_device.hpp"
 #include "tfq_vec.hpp"
 
@@ -166,18 +168,21 @@ __global__ __launch_bounds__(256) void k_xpay_v6(DevPlan d) {
     if (t >= G::T) return;
     R const* v5 = (R const*)d.v5; R* v6 = (R*)d.v6;
     Scal<R, LN, G::VEC> beta; beta.load((R const*)d.beta, col, t, d.ilv);
-    for (uint32_t w = t; w < nItems; w += G::T) {
-        TFQ_ITEM_OFFSETS(G)
-        R xr[G::VEC], xi[G::VEC], yr[G::VEC], yi[G::VEC];
-        ldv(xr, v5 + re); ldv(xi, v5 + im);
-        if (d.first) {                                   // v6 = 0 at the start of a solve: not read (same arithmetic on zeros)
+    auto sweep = [&](auto first) __attribute__((always_inline)) {   // two loops, not a branch per trip (a branch inside cost k_x_v6_v7 2.4 %)
+        for (uint32_t w = t; w < nItems; w += G::T) {
+            TFQ_ITEM_OFFSETS(G)
+            R xr[G::VEC], xi[G::VEC], yr[G::VEC], yi[G::VEC];
+            ldv(xr, v5 + re); ldv(xi, v5 + im);
+            if constexpr (decltype(first)::value) {          // v6 = 0 at the start of a solve: not read (same arithmetic on zeros)
 #pragma unroll
-            for (int v = 0; v < G::VEC; ++v) { yr[v] = 0; yi[v] = 0; }
-        } else { ldv(yr, v6 + re); ldv(yi, v6 + im); }
+                for (int v = 0; v < G::VEC; ++v) { yr[v] = 0; yi[v] = 0; }
+            } else { ldv(yr, v6 + re); ldv(yi, v6 + im); }
 #pragma unroll
-        for (int v = 0; v < G::VEC; ++v) xpay(yr[v], yi[v], xr[v], xi[v], beta.re[v], beta.im[v]);
-        stv(v6 + re, yr); stv(v6 + im, yi);
-    }
+            for (int v = 0; v < G::VEC; ++v) xpay(yr[v], yi[v], xr[v], xi[v], beta.re[v], beta.im[v]);
+            stv(v6 + re, yr); stv(v6 + im, yi);
+        }
+    };
+    if (d.first) sweep(std::true_type{}); else sweep(std::false_type{});
 }
 
 // ---- KC: v5 := alfa v9 + v5 ; pd <- |v5|^2 ---------------------------------------------------------
@@ -223,24 +228,27 @@ __global__ __launch_bounds__(256) void k_x_v6_v7(DevPlan d) {
     Scal<R, LN, G::VEC> eta, eta2, alfa, c67, c67a;
     eta.load((R const*)d.eta, col, t, d.ilv); eta2.load((R const*)d.eta2, col, t, d.ilv); alfa.load((R const*)d.alfa, col, t, d.ilv);
     c67.load((R const*)d.c67, col, t, d.ilv); c67a.load((R const*)d.c67a, col, t, d.ilv);
-    for (uint32_t w = t; w < nItems; w += G::T) {
-        TFQ_ITEM_OFFSETS(G)
-        R sr[G::VEC], si[G::VEC], xr[G::VEC], xi[G::VEC], ar[G::VEC], ai[G::VEC], br[G::VEC], bi[G::VEC];
-        if (d.first) {                                   // v7 = x = 0 at the start of a solve: not read (same arithmetic on zeros)
+    auto sweep = [&](auto first) __attribute__((always_inline)) {   // two loops, not a branch per trip (measured: 2.4 %)
+        for (uint32_t w = t; w < nItems; w += G::T) {
+            TFQ_ITEM_OFFSETS(G)
+            R sr[G::VEC], si[G::VEC], xr[G::VEC], xi[G::VEC], ar[G::VEC], ai[G::VEC], br[G::VEC], bi[G::VEC];
+            if constexpr (decltype(first)::value) {          // v7 = x = 0 at the start of a solve: not read (same arithmetic on zeros)
 #pragma unroll
-            for (int v = 0; v < G::VEC; ++v) { sr[v] = 0; si[v] = 0; xr[v] = 0; xi[v] = 0; }
-        } else { ldv(sr, v7 + re); ldv(si, v7 + im); ldv(xr, x + re); ldv(xi, x + im); }
-        ldv(ar, v4 + re); ldv(ai, v4 + im); ldv(br, v6 + re); ldv(bi, v6 + im);
+                for (int v = 0; v < G::VEC; ++v) { sr[v] = 0; si[v] = 0; xr[v] = 0; xi[v] = 0; }
+            } else { ldv(sr, v7 + re); ldv(si, v7 + im); ldv(xr, x + re); ldv(xi, x + im); }
+            ldv(ar, v4 + re); ldv(ai, v4 + im); ldv(br, v6 + re); ldv(bi, v6 + im);
 #pragma unroll
-        for (int v = 0; v < G::VEC; ++v) {
-            if (pend) axpy(xr[v], xi[v], sr[v], si[v], eta2.re[v], eta2.im[v]);  // x  += eta2 v7   (previous iteration)
-            xpay(sr[v], si[v], br[v], bi[v], c67a.re[v], c67a.im[v]);           // v7  = v6 + c67a v7
-            axpy(xr[v], xi[v], sr[v], si[v], eta.re[v], eta.im[v]);             // x  += eta  v7
-            axpy(br[v], bi[v], ar[v], ai[v], alfa.re[v], alfa.im[v]);           // v6 += alfa v4
-            xpay(sr[v], si[v], br[v], bi[v], c67.re[v], c67.im[v]);             // v7  = v6 + c67 v7
+            for (int v = 0; v < G::VEC; ++v) {
+                if (pend) axpy(xr[v], xi[v], sr[v], si[v], eta2.re[v], eta2.im[v]);  // x  += eta2 v7   (previous iteration)
+                xpay(sr[v], si[v], br[v], bi[v], c67a.re[v], c67a.im[v]);           // v7  = v6 + c67a v7
+                axpy(xr[v], xi[v], sr[v], si[v], eta.re[v], eta.im[v]);             // x  += eta  v7
+                axpy(br[v], bi[v], ar[v], ai[v], alfa.re[v], alfa.im[v]);           // v6 += alfa v4
+                xpay(sr[v], si[v], br[v], bi[v], c67.re[v], c67.im[v]);             // v7  = v6 + c67 v7
+            }
+            stv(x + re, xr); stv(x + im, xi); stv(v6 + re, br); stv(v6 + im, bi); stv(v7 + re, sr); stv(v7 + im, si);
         }
-        stv(x + re, xr); stv(x + im, xi); stv(v6 + re, br); stv(v6 + im, bi); stv(v7 + re, sr); stv(v7 + im, si);
-    }
+    };
+    if (d.first) sweep(std::true_type{}); else sweep(std::false_type{});
 }
 
 // ---- KF: x := eta2 v7 + x, only when the true residual is about to be computed (tfqmrgpu_core.hxx:233) ---
