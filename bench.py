@@ -290,13 +290,14 @@ def main():
             nPairs = view["nPairs"]
             nA_ref = len(np.unique(view["pairs"][0::2]))
             model = kernel_model(pr, prec, nPairs, nA_ref)
-            # avg_ms: launches that did work; avg_ms_all_launches also counts the launches that were enqueued ahead
-            # of the stopping decision and returned at once (what a profiler's per-kernel average shows)
+            # avg_ms: launches that did work in steady iterations; avg_ms_all_launches also counts the launches that were enqueued ahead
+            # of the stopping decision and returned at once (what a profiler's per-kernel average shows: the first-iteration launches
+            # of the interleaved multiplies are kernel instances of their own, <..., FIRST = true>, and are not in either)
             for a in prof.values():      # a solve of ONE iteration has no steady launch: its first-iteration launches stand in
                 if a[0] == 0 and a[4] > 0:
                     a[0], a[1] = a[4], a[5]
             per_kernel = {k: dict(launches=n, avg_ms=round(ms / n, 5), total_ms=round(ms, 3), gated_off_launches=gn,
-                                  avg_ms_all_launches=round((ms + gms + fms) / (n + gn + fn), 5), first_iteration_launches=fn,
+                                  avg_ms_all_launches=round((ms + gms) / (n + gn), 5), first_iteration_launches=fn,
                                   avg_ms_first_iteration=round(fms / fn, 5) if fn else None)
                           for k, (n, ms, gn, gms, fn, fms) in prof.items() if n}
             def roof_of(k):

@@ -1,12 +1,12 @@
 #!/bin/bash
 source scripts/gpu_steps.sh
 for r in 1 2; do
-step 600 ab_lambda_$r.json python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-hbm-multiply
+step 600 ab_tmpl_$r.json python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-hbm-multiply
 step 600 ab_branch_$r.json env TFQMRGPU_LIB=$PWD/scripts/bin/branch/libtfQMRgpu.so python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-hbm-multiply
 done
 python3 - <<'PY'
 import json
-for t in ("lambda_1","branch_1","lambda_2","branch_2"):
+for t in ("tmpl_1","branch_1","tmpl_2","branch_2"):
     d=json.loads([l for l in open("gpurun_out/ab_%s.json" % t) if l.startswith("{")][-1])
     k=d["kernels"]
     print(t, d["value"], d["ms_per_step"], "v4", k["spmm_v4_dot"]["avg_ms"], k["spmm_v4_dot"]["avg_ms_first_iteration"], "v5", k["spmm_v5_nrm_dot"]["avg_ms"], "x", k["x_v6_v7"]["avg_ms"], "it", d["roofline_iteration"]["ms_per_iteration"])

@@ -622,7 +622,7 @@ using f2v = __attribute__((ext_vector_type(2))) float;
 // once per multiply -- the kernel is a stream of A through HBM, and 16-byte non-temporal loads take it from 5.5 to 6.6 TB/s
 // (one block column, 1.3 GB of A: plain multiply 0.69 -> 0.82 of 8 TB/s, fused 0.76 -> 0.85, profiles/r02_lab.txt); with
 // many columns A is re-used out of the caches and must stay there (the plan decides: SpmmArgs::aOnce).
-template <int EPI, bool HASH, bool ANT = false>
+template <int EPI, bool HASH, bool ANT = false, bool FIRST = false>   // FIRST: the launch of the first iteration of a solve (SpmmArgs::first)
 __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
     if (gate_closed(a)) return;
     using R = double;
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
         if constexpr (UPD) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {   // old v4 | v5, v8, v3: touched once, non-temporal
-                if (EPI == EPI_XPAY_DOT && a.first) { ur[h] = d2v{0, 0}; ui[h] = d2v{0, 0}; vr[h] = d2v{0, 0}; vi[h] = d2v{0, 0}; }   // first iteration: old v4 = v8 = 0, not read
+                if constexpr (EPI == EPI_XPAY_DOT && FIRST) { ur[h] = d2v{0, 0}; ui[h] = d2v{0, 0}; vr[h] = d2v{0, 0}; vi[h] = d2v{0, 0}; }   // first iteration: old v4 = v8 = 0, not read
                 else {
                 ur[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff + eb[h])); ui[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff + eb[h] + P));
                 if constexpr (EPI == EPI_XPAY_DOT) { vr[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff + eb[h])); vi[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff + eb[h] + P)); }
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
 // default shape of the reference's own benchmark (`bench_tfqmrgpu multi`, bench_tfqmrgpu.cu:445-450).
 using f4v = __attribute__((ext_vector_type(4))) float;
 
-template <int EPI, bool HASH, bool ANT = false>
+template <int EPI, bool HASH, bool ANT = false, bool FIRST = false>   // FIRST: the launch of the first iteration of a solve (SpmmArgs::first)
 __global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
     if (gate_closed(a)) return;
     using R = float;
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
         size_t const yoff = size_t(y) * 2 * P + mine;          // rows 4 lr .. 4 lr + 3 of column lc
         f4v ur, ui, vr, vi, wr, wi;
         if constexpr (UPD) {
-            if (EPI == EPI_XPAY_DOT && a.first) { ur = f4v{0, 0, 0, 0}; ui = ur; vr = ur; vi = ur; }   // first iteration: old v4 = v8 = 0, not read
+            if constexpr (EPI == EPI_XPAY_DOT && FIRST) { ur = f4v{0, 0, 0, 0}; ui = ur; vr = ur; vi = ur; }   // first iteration: old v4 = v8 = 0, not read
             else {
             ur = __builtin_nontemporal_load((f4v const*)((R const*)a.e0 + yoff)); ui = __builtin_nontemporal_load((f4v const*)((R const*)a.e0 + yoff + P));
             if constexpr (EPI == EPI_XPAY_DOT) { vr = __builtin_nontemporal_load((f4v const*)((R const*)a.e1 + yoff)); vi = __builtin_nontemporal_load((f4v const*)((R const*)a.e1 + yoff + P)); }
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
 // bytes in k_spmm_mfma<float, 32, 32>), and every accumulator tile is one 16-byte piece of each epilogue vector (8-byte pieces there).
 // The ablations of profiles/r02_ab_config3.txt are why: that kernel gains time with every operand load instruction that is removed.
 // No epilogue-operand prefetch (the registers of the tiles: three waves per SIMD matter more), v3 is read.
-template <int LM, int LN, int EPI>
+template <int LM, int LN, int EPI, bool FIRST = false>   // FIRST: the launch of the first iteration of a solve (SpmmArgs::first)
 __global__ __launch_bounds__(256, (LN <= 32 ? 3 : 2)) void k_spmm_ilvf(SpmmArgs a) {   // 32 columns: three waves per SIMD (168 VGPRs at most; 64 columns would spill)
     if (gate_closed(a)) return;
     using R = float;
@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(256, (LN <= 32 ? 3 : 2)) void k_spmm_ilvf(SpmmArgs 
                 size_t const yoff = size_t(y) * 2 * P + at;
                 f4v ur, ui, vr, vi, wr, wi;
                 if constexpr (UPD) {
-                    if (EPI == EPI_XPAY_DOT && a.first) { ur = f4v{0, 0, 0, 0}; ui = ur; vr = ur; vi = ur; }   // first iteration: old v4 = v8 = 0, not read
+                    if constexpr (EPI == EPI_XPAY_DOT && FIRST) { ur = f4v{0, 0, 0, 0}; ui = ur; vr = ur; vi = ur; }   // first iteration: old v4 = v8 = 0, not read
                     else {
                     ur = __builtin_nontemporal_load((f4v const*)((R const*)a.e0 + yoff)); ui = __builtin_nontemporal_load((f4v const*)((R const*)a.e0 + yoff + P));
                     if constexpr (EPI == EPI_XPAY_DOT) { vr = __builtin_nontemporal_load((f4v const*)((R const*)a.e1 + yoff)); vi = __builtin_nontemporal_load((f4v const*)((R const*)a.e1 + yoff + P)); }
@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(256, (LN <= 32 ? 3 : 2)) void k_spmm_ilvf(SpmmArgs 
 __device__ inline double xor8(double v) { return __shfl_xor(v, 8); }
 __device__ inline d2v xor8(d2v v) { return d2v{__shfl_xor(v[0], 8), __shfl_xor(v[1], 8)}; }
 
-template <int EPI, bool HASH>
+template <int EPI, bool HASH, bool FIRST = false>   // FIRST: the launch of the first iteration of a solve (SpmmArgs::first)
 __global__ __launch_bounds__(256) void k_spmm_ilv8(SpmmArgs a) {
     if (gate_closed(a)) return;
     using R = double;
@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8(SpmmArgs a) {
         size_t const yoff = size_t(y) * 2 * P + mine;
         d2v uM = d2v{0, 0}, vM = d2v{0, 0}; f2v wM = f2v{0, 0};
         if constexpr (UPD) {                       // the epilogue operands travel while the products are computed
-            if (!(EPI == EPI_XPAY_DOT && a.first)) {   // (first iteration of a solve: old v4 = v8 = 0, not read)
+            if constexpr (!(EPI == EPI_XPAY_DOT && FIRST)) {   // (first iteration of a solve: old v4 = v8 = 0, not read)
             uM = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff));
             if constexpr (EPI == EPI_XPAY_DOT) vM = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff));
             }
@@ -1475,6 +1475,13 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
         if (a.ilv && a.chunkFirst) {   // the plan keeps its blocks row-pair-interleaved (tfq_plan.cpp: layoutBuffer); never the plain mode
             constexpr bool canHashI = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
             bool const hash = canHashI && a.hashV3;
+            // (the first-iteration launch of EPI_XPAY_DOT is its own instance: a test of the flag per Y block costs the steady launches 0.5 %)
+            constexpr bool canFirst = (EPI == EPI_XPAY_DOT);
+            if (canFirst && a.first) {
+                if (a.aOnce) { if (hash) k_spmm_ilv16<EPI, canHashI, true, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16<EPI, false, true, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a); }
+                else         { if (hash) k_spmm_ilv16<EPI, canHashI, false, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16<EPI, false, false, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a); }
+                return;
+            }
             if (a.aOnce) { if (hash) k_spmm_ilv16<EPI, canHashI, true><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16<EPI, false, true><<<dim3(nWG), dim3(256), 0, s>>>(a); }
             else         { if (hash) k_spmm_ilv16<EPI, canHashI, false><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16<EPI, false, false><<<dim3(nWG), dim3(256), 0, s>>>(a); }
             return;
@@ -1484,17 +1491,34 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
         if (4 == a.ilv && a.chunkFirst) {   // quads of rows interleaved
             constexpr bool canHashF = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
             bool const hash = canHashF && a.hashV3;
+            constexpr bool canFirst = (EPI == EPI_XPAY_DOT);
+            if (canFirst && a.first) {
+                if (a.aOnce) { if (hash) k_spmm_ilv16f<EPI, canHashF, true, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16f<EPI, false, true, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a); }
+                else         { if (hash) k_spmm_ilv16f<EPI, canHashF, false, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16f<EPI, false, false, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a); }
+                return;
+            }
             if (a.aOnce) { if (hash) k_spmm_ilv16f<EPI, canHashF, true><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16f<EPI, false, true><<<dim3(nWG), dim3(256), 0, s>>>(a); }
             else         { if (hash) k_spmm_ilv16f<EPI, canHashF, false><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16f<EPI, false, false><<<dim3(nWG), dim3(256), 0, s>>>(a); }
             return;
         }
     }
     if constexpr (sizeof(R) == 4 && LM % 16 == 0 && LN == 32) {   // (64 columns: measured level with or behind k_spmm_mfma, whose lanes already move 16 bytes there)
-        if (4 == a.ilv && a.chunkFirst) { k_spmm_ilvf<LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a); return; }
+        if (4 == a.ilv && a.chunkFirst) {
+            constexpr bool canFirst = (EPI == EPI_XPAY_DOT);
+            if (canFirst && a.first) k_spmm_ilvf<LM, LN, EPI, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a);
+            else k_spmm_ilvf<LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
+            return;
+        }
     }
     if constexpr (LM == 8 && LN == 8 && sizeof(R) == 8) {
         if (a.ilv && a.chunkFirst) {
             constexpr bool canHash8 = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
+            constexpr bool canFirst = (EPI == EPI_XPAY_DOT);
+            if (canFirst && a.first) {
+                if (canHash8 && a.hashV3) k_spmm_ilv8<EPI, canHash8, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a);
+                else k_spmm_ilv8<EPI, false, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a);
+                return;
+            }
             if (canHash8 && a.hashV3) k_spmm_ilv8<EPI, canHash8><<<dim3(nWG), dim3(256), 0, s>>>(a);
             else k_spmm_ilv8<EPI, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
             return;
