@@ -58,9 +58,10 @@ tfqmrgpuStatus_t tfqmrgpuExt_getProfile(tfqmrgpuBsrsvPlan_t plan, int64_t *launc
 /* the launches that were enqueued ahead of the stopping decision and returned without doing work
  * (a profiler counts them as calls of the same kernels) */
 tfqmrgpuStatus_t tfqmrgpuExt_getProfileGated(tfqmrgpuBsrsvPlan_t plan, int64_t *launches, double *milliseconds);
-/* of the launches that getProfile counts: those of the FIRST iteration of the solve.  v4, v6, v7, v8 and x are zero there by
- * definition (tfqmrgpu_core.hxx:125,147-151) and are neither cleared at the start of a solve nor read: XPAY_V6, SPMM_V4_DOT
- * and X_V6_V7 move 1, 2 and 2 vectors less in that launch -- price a kernel against its roof on the other launches. */
+/* of the launches that getProfile counts: those of the FIRST iteration of the solve.  v4, v6, v7, v8 and x are zero there and v5 is
+ * B scattered onto zeros by definition (tfqmrgpu_core.hxx:125,147-153); they are neither written at the start of a solve nor
+ * read: XPAY_V6, SPMM_V4_DOT, V5_NRM and X_V6_V7 move 2, 2, 1 and 2 vectors less in that launch -- price a kernel against its
+ * roof on the other launches. */
 tfqmrgpuStatus_t tfqmrgpuExt_getProfileFirst(tfqmrgpuBsrsvPlan_t plan, int64_t *launches, double *milliseconds);
 
 /* ---- (2) shadow vector v3 -------------------------------------------------------------- */

@@ -310,7 +310,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
             mark(TFQMRGPU_PROF_XPAY_V6);          (void)vec_launch(VEC_XPAY_V6, dSlot, 0, 0, s);
             mark(TFQMRGPU_PROF_SPMM_V4_DOT);      multiply(EPI_XPAY_DOT, dSlot);
             mark(TFQMRGPU_PROF_DEC34);            (void)vec_launch(VEC_DEC34, d, 0, 0, s);
-            mark(TFQMRGPU_PROF_V5_NRM);           (void)vec_launch(VEC_V5_NRM, d, 0, 0, s);
+            mark(TFQMRGPU_PROF_V5_NRM);           (void)vec_launch(VEC_V5_NRM, dSlot, 0, 0, s);
             mark(TFQMRGPU_PROF_DECT_C67);         (void)vec_launch(VEC_DECT_C67, d, 0, 0, s);
             mark(TFQMRGPU_PROF_X_V6_V7);          (void)vec_launch(VEC_X_V6_V7, dSlot, 0, 0, s);
             mark(TFQMRGPU_PROF_SPMM_V5_NRM_DOT);  multiply(EPI_AXPY_NRM_DOT, dSlot);

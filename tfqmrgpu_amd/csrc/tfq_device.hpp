@@ -39,8 +39,9 @@ struct DevPlan {
     int ilv;                                   // element order inside a block plane: 0 native [r][s], G = 2 | 4: groups of G rows interleaved (see ilv_offset)
     int aOnce;                                 // a multiply uses every A block about once (<= 1.5 times): A is streamed, not cached
     int first;                                 // set by the host for the launches of the FIRST iteration of a solve: v4, v6, v7, v8 and x are
-                                               // zero by definition there (tfqmrgpu_core.hxx:125,147-151) -- the kernels do not read them, and
-                                               // the start of a solve does not clear them (10 S of traffic per solve)
+                                               // zero and v5 is B scattered onto zeros by definition there (tfqmrgpu_core.hxx:125,147-153) --
+                                               // the kernels take that as given instead of reading it, and the start of a solve writes none of
+                                               // them (13 S of traffic per solve)
     void *x, *v4, *v5, *v6, *v7, *v8, *v9, *B, *A;
     float* v3;
     void *rho, *alfa, *beta, *c67, *eta;       // [nCols][2][LN] real

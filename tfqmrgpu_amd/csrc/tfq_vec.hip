@@ -137,19 +137,32 @@ __device__ inline void chunk_reduce(double (&acc)[NPL][VEC], double* s, double* 
     size_t const re = base + size_t(blk) * 2 * G::P + size_t(w - blk * G::IPB) * G::VEC; \
     size_t const im = re + G::P;
 
+// At the start of a solve v5 is B scattered onto zeros (tfqmrgpu_core.hxx:153): the kernels of the first iteration that read it
+// take the B block under an X block (bOfX), or zeros, directly -- v5 itself is first WRITTEN by k_v5_nrm of that iteration.
+template <typename R, int VEC>
+__device__ inline void ld_rhs(R (&r)[VEC], R (&i)[VEC], DevPlan const& d, uint32_t xblock, size_t inner, int P) {
+    uint32_t const bq = d.bOfX[xblock];
+    if (0xffffffffu == bq) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { r[v] = 0; i[v] = 0; }
+    } else {
+        R const* b = (R const*)d.B + size_t(bq) * 2 * P + inner;
+        ldv(r, b); ldv(i, b + P);
+    }
+}
+
 // ---- K0: pz <- v3 . v5 (unconjugated), start of a solve -------------------------------------------
 template <typename R, int LM, int LN>
 __global__ __launch_bounds__(256) void k_dot35(DevPlan d) {
     using G = Geo<R, LM, LN>;
     __shared__ double s[2 * 256 * G::VEC];
     TFQ_CHUNK_PROLOGUE(G)
-    R const* v5 = (R const*)d.v5;
     double acc[2][G::VEC] = {};
     if (t < G::T) for (uint32_t w = t; w < nItems; w += G::T) {
         TFQ_ITEM_OFFSETS(G)
-        if (0xffffffffu == d.bOfX[first + blk]) continue;   // v5 is B scattered onto zeros at this point: only blocks under a B block count
+        if (0xffffffffu == d.bOfX[first + blk]) continue;   // v5 = B scattered onto zeros: only blocks under a B block count
         R ar[G::VEC], ai[G::VEC]; float wr[G::VEC], wi[G::VEC];
-        ldv(ar, v5 + re); ldv(ai, v5 + im); ldf(wr, d.v3 + re); ldf(wi, d.v3 + im);
+        ld_rhs<R, G::VEC>(ar, ai, d, first + blk, size_t(w - blk * G::IPB) * G::VEC, G::P); ldf(wr, d.v3 + re); ldf(wi, d.v3 + im);
 #pragma unroll
         for (int v = 0; v < G::VEC; ++v) {
             double const xr = ar[v], xi = ai[v], yr = wr[v], yi = wi[v];
@@ -168,15 +181,15 @@ __global__ __launch_bounds__(256) void k_xpay_v6(DevPlan d) {
     if (t >= G::T) return;
     R const* v5 = (R const*)d.v5; R* v6 = (R*)d.v6;
     Scal<R, LN, G::VEC> beta; beta.load((R const*)d.beta, col, t, d.ilv);
-    auto sweep = [&](auto first) __attribute__((always_inline)) {   // two loops, not a branch per trip (a branch inside cost k_x_v6_v7 2.4 %)
+    auto sweep = [&](auto firstTag) __attribute__((always_inline)) {   // two loops, not a branch per trip (a branch inside cost k_x_v6_v7 2.4 %)
         for (uint32_t w = t; w < nItems; w += G::T) {
             TFQ_ITEM_OFFSETS(G)
             R xr[G::VEC], xi[G::VEC], yr[G::VEC], yi[G::VEC];
-            ldv(xr, v5 + re); ldv(xi, v5 + im);
-            if constexpr (decltype(first)::value) {          // v6 = 0 at the start of a solve: not read (same arithmetic on zeros)
+            if constexpr (decltype(firstTag)::value) {       // v5 = B on zeros, v6 = 0 at the start of a solve: not read (same arithmetic)
+                ld_rhs<R, G::VEC>(xr, xi, d, first + blk, size_t(w - blk * G::IPB) * G::VEC, G::P);
 #pragma unroll
                 for (int v = 0; v < G::VEC; ++v) { yr[v] = 0; yi[v] = 0; }
-            } else { ldv(yr, v6 + re); ldv(yi, v6 + im); }
+            } else { ldv(xr, v5 + re); ldv(xi, v5 + im); ldv(yr, v6 + re); ldv(yi, v6 + im); }
 #pragma unroll
             for (int v = 0; v < G::VEC; ++v) xpay(yr[v], yi[v], xr[v], xi[v], beta.re[v], beta.im[v]);
             stv(v6 + re, yr); stv(v6 + im, yi);
@@ -197,18 +210,23 @@ __global__ __launch_bounds__(256) void k_v5_nrm(DevPlan d) {
     double acc[1][G::VEC] = {};
     if (t < G::T) {
         Scal<R, LN, G::VEC> alfa; alfa.load((R const*)d.alfa, col, t, d.ilv);
-        for (uint32_t w = t; w < nItems; w += G::T) {
-            TFQ_ITEM_OFFSETS(G)
-            R ar[G::VEC], ai[G::VEC], br[G::VEC], bi[G::VEC];
-            ldv(ar, v9 + re); ldv(ai, v9 + im); ldv(br, v5 + re); ldv(bi, v5 + im);
+        auto sweep = [&](auto firstTag) __attribute__((always_inline)) {
+            for (uint32_t w = t; w < nItems; w += G::T) {
+                TFQ_ITEM_OFFSETS(G)
+                R ar[G::VEC], ai[G::VEC], br[G::VEC], bi[G::VEC];
+                ldv(ar, v9 + re); ldv(ai, v9 + im);
+                if constexpr (decltype(firstTag)::value) ld_rhs<R, G::VEC>(br, bi, d, first + blk, size_t(w - blk * G::IPB) * G::VEC, G::P);   // v5 = B on zeros: first written here
+                else { ldv(br, v5 + re); ldv(bi, v5 + im); }
 #pragma unroll
-            for (int v = 0; v < G::VEC; ++v) {
-                axpy(br[v], bi[v], ar[v], ai[v], alfa.re[v], alfa.im[v]);
-                double const r = br[v], i = bi[v];
-                acc[0][v] = __builtin_fma(i, i, __builtin_fma(r, r, acc[0][v]));
+                for (int v = 0; v < G::VEC; ++v) {
+                    axpy(br[v], bi[v], ar[v], ai[v], alfa.re[v], alfa.im[v]);
+                    double const r = br[v], i = bi[v];
+                    acc[0][v] = __builtin_fma(i, i, __builtin_fma(r, r, acc[0][v]));
+                }
+                stv(v5 + re, br); stv(v5 + im, bi);
             }
-            stv(v5 + re, br); stv(v5 + im, bi);
-        }
+        };
+        if (d.first) sweep(std::true_type{}); else sweep(std::false_type{});
     }
     chunk_reduce<LN, G::VEC, G::T, 1>(acc, s, d.pd + size_t(chunk) * LN, t, d.ilv);
 }
@@ -488,16 +506,6 @@ __global__ __launch_bounds__(256) void k_decide(DevPlan d, int what, int phase) 
 }
 
 // ---- start of a solve ---------------------------------------------------------------------------
-// v5[subset[b]] := B[b]   (add_RHS onto the cleared v5, tfqmrgpu_core.hxx:153)
-template <typename R, int LM, int LN>
-__global__ __launch_bounds__(256) void k_scatter_B(DevPlan d) {
-    constexpr int E = 2 * LM * LN;
-    uint32_t const b = blockIdx.x;
-    R const* src = (R const*)d.B + size_t(b) * E;
-    R* dst = (R*)d.v5 + size_t(d.subset[b]) * E;
-    for (int e = threadIdx.x; e < E; e += 256) dst[e] = src[e];
-}
-
 // tau := |b|^2 per RHS, 1/|b|^2, rho := 1, everything else 0 (tfqmrgpu_core.hxx:121-127,154-166)
 template <typename R, int LM, int LN>
 __global__ __launch_bounds__(256) void k_init_col(DevPlan d, double tol, int maxIterations) {
@@ -550,11 +558,10 @@ static hipError_t vec_run(int op, DevPlan const& d, double tol, int maxIt, hipSt
     switch (op) {
     case VEC_SETUP: {
         size_t const S = size_t(d.nnzbX) * 2 * LM * LN * sizeof(R);
-        // only v5 is cleared (B is scattered onto it): x, v4, v6, v7, v8 are zero by definition in the first iteration and its
-        // kernels do not read them (DevPlan::first), v9 is written before it is read.  No iteration at all: x is the answer, zero.
-        if (auto const e = hipMemsetAsync(d.v5, 0, S, s)) return e;
+        // nothing is cleared: x, v4, v6, v7, v8 are zero and v5 is B scattered onto zeros by definition in the first iteration, whose
+        // kernels take that as given instead of reading it (DevPlan::first); v9 is written before it is read.
+        // No iteration at all: x is the answer, zero.
         if (maxIt <= 0) if (auto const e = hipMemsetAsync(d.x, 0, S, s)) return e;
-        if (d.nnzbB) k_scatter_B<R, LM, LN><<<dim3(d.nnzbB), blk, 0, s>>>(d);
         k_init_col<R, LM, LN><<<cols, blk, 0, s>>>(d, tol, maxIt);
         k_dot35<R, LM, LN><<<grid, blk, 0, s>>>(d);
     } break;
