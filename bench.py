@@ -73,8 +73,11 @@ def build_problem(name, rank, world=1):
     return pr, prec, desc
 
 
-def kernel_model(pr, prec, nPairs, nA_ref):
-    """algorithmic bytes and flops per launch of each kernel class of one iteration"""
+def kernel_model(pr, prec, nPairs, nA_ref, hash_in_registers=False):
+    """algorithmic bytes and flops per launch of each kernel class of one iteration: (bytes the kernel has to
+    move, flops, bytes by the model of SURVEY Appendix D).  The two differ for the fused multiplies of the shapes whose kernels
+    recompute the shadow vector v3 from its hash in registers (16x16 z | c, 8x8 z in the default shadow mode): the model counts
+    v3 (S/2 in z, S in c), the kernel never reads it -- pricing it with bytes it does not move would flatter it."""
     rb = 8 if prec == "z" else 4
     S = pr.nnzbX * 2 * pr.LM * pr.LN * rb            # one X-shaped vector
     S3 = pr.nnzbX * 2 * pr.LM * pr.LN * 4            # the float shadow vector
@@ -82,14 +85,20 @@ def kernel_model(pr, prec, nPairs, nA_ref):
     idx = 4 * (pr.nnzbX + 1) + 8 * nPairs
     fm = nPairs * 8.0 * pr.LM * pr.LM * pr.LN
     el = pr.nnzbX * pr.LM * pr.LN
+    S3m = 0 if hash_in_registers else S3
     return {
-        "xpay_v6": (3 * S, 8.0 * el),
-        "spmm_v4_dot": (5 * S + S3 + A + idx, fm + 24.0 * el),
-        "v5_nrm": (3 * S, 12.0 * el),
-        "x_v6_v7": (7 * S, 40.0 * el),
-        "spmm_v5_nrm_dot": (4 * S + S3 + A + idx, fm + 20.0 * el),
-        "multiply": (2 * S + A + idx, fm),
+        "xpay_v6": (3 * S, 8.0 * el, 3 * S),
+        "spmm_v4_dot": (5 * S + S3m + A + idx, fm + 24.0 * el, 5 * S + S3 + A + idx),
+        "v5_nrm": (3 * S, 12.0 * el, 3 * S),
+        "x_v6_v7": (7 * S, 40.0 * el, 7 * S),
+        "spmm_v5_nrm_dot": (4 * S + S3m + A + idx, fm + 20.0 * el, 4 * S + S3 + A + idx),
+        "multiply": (2 * S + A + idx, fm, 2 * S + A + idx),
     }
+
+
+def hash_shapes(prec, LM, LN):
+    """shapes whose fused multiplies recompute the hash shadow vector in registers (tfq_spmm.hip: spmm_go)"""
+    return (LM, LN) == (16, 16) or (prec == "z" and (LM, LN) == (8, 8))
 
 
 def S_bytes(pr, prec):
@@ -289,7 +298,7 @@ def main():
         if rank == 0:
             nPairs = view["nPairs"]
             nA_ref = len(np.unique(view["pairs"][0::2]))
-            model = kernel_model(pr, prec, nPairs, nA_ref)
+            model = kernel_model(pr, prec, nPairs, nA_ref, hash_in_registers=hash_shapes(prec, pr.LM, pr.LN))
             # avg_ms: launches that did work in steady iterations; avg_ms_all_launches also counts the launches that were enqueued ahead
             # of the stopping decision and returned at once (what a profiler's per-kernel average shows: the first-iteration launches
             # of the interleaved multiplies are kernel instances of their own, <..., FIRST = true>, and are not in either)
@@ -302,9 +311,14 @@ def main():
                           for k, (n, ms, gn, gms, fn, fms) in prof.items() if n}
             def roof_of(k):
                 r = roof(model[k][0], model[k][1], per_kernel[k]["avg_ms"], prec)
+                rm_ = roof(model[k][2], model[k][1], per_kernel[k]["avg_ms"], prec)
                 r.update(kernel=k, avg_ms=per_kernel[k]["avg_ms"], launches=per_kernel[k]["launches"],
                          gated_off_launches=per_kernel[k]["gated_off_launches"], avg_ms_all_launches=per_kernel[k]["avg_ms_all_launches"],
-                         algorithmic_bytes=int(model[k][0]), algorithmic_flops=float(model[k][1]), traffic=None)
+                         algorithmic_bytes=int(model[k][0]), algorithmic_flops=float(model[k][1]), traffic=None,
+                         # `achieved` / `frac` price the bytes the kernel has to move; the *_model figures use SURVEY Appendix D's byte
+                         # model, which counts the shadow vector even where the kernel recomputes it in registers
+                         algorithmic_bytes_moved=int(model[k][0]), algorithmic_bytes_model=int(model[k][2]),
+                         achieved_model=rm_["achieved"], frac_model=rm_["frac"])
                 return r
             # `roofline` = the BSR multiply of the north star: of the two fused multiply kernels the one with more summed time
             # (the kernel VERDICT r01 named).  When a vector kernel has more summed time than that, it is reported next to it
@@ -319,6 +333,8 @@ def main():
             if os.path.exists(tp):   # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc cannot run inside this timing run)
                 rl["traffic"] = json.load(open(tp)).get(args.workload, {}).get(dom)
             if rl["traffic"] is not None:
+                rl["traffic_over_moved"] = round(rl["traffic"] / rl["algorithmic_bytes_moved"], 3)
+                rl["traffic_over_model"] = round(rl["traffic"] / rl["algorithmic_bytes_model"], 3)
                 rl["traffic_source"] = "profiles/pmc_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE of scripts/pmc_collect.sh, kept from the latest PMC run; not measured in this run)"
 
             # The BSR multiply Y = A*X on its own, twice:

@@ -33,15 +33,24 @@ void FN(tfqo_spmm)(int LM, int LN, uint32_t nnzbY, uint32_t const *starts, uint3
             REAL const *x = X + (size_t)pairs[2 * (size_t)p + 1] * 2 * P;
             for (int i = 0; i < LM; ++i) {
                 for (int j = 0; j < LN; ++j) {
+#ifdef TFQO_RUNNING_SUM   /* sensitivity probe only (tests/test_oracle_sensitivity.py): ONE running sum over all products of a Y element */
+                    REAL re = y[(size_t)i * LN + j], im = y[P + (size_t)i * LN + j];
+#else
                     REAL re = 0, im = 0;
+#endif
                     for (int k = 0; k < LM; ++k) {
                         REAL const ar = a[(size_t)k * LM + i], ai = a[Q + (size_t)k * LM + i];
                         REAL const xr = x[(size_t)k * LN + j], xi = x[P + (size_t)k * LN + j];
                         re += ar * xr - ai * xi;
                         im += ar * xi + ai * xr;
                     }
+#ifdef TFQO_RUNNING_SUM
+                    y[(size_t)i * LN + j] = re;
+                    y[P + (size_t)i * LN + j] = im;
+#else
                     y[(size_t)i * LN + j] += re;
                     y[P + (size_t)i * LN + j] += im;
+#endif
                 }
             }
         }

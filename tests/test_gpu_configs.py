@@ -66,6 +66,21 @@ def torch_cuda():
     return torch
 
 
+def test_config2_P2_full_size(torch_cuda, oracle):
+    # BASELINE config 2 at the size bench.py times it (`generate_FD_example 16 120 4 2 -0.25`: 16x16 complex<double>, 3573 block rows,
+    # 49 block columns = 784 right-hand sides, 138 229 X blocks, 679 189 block products per multiply): the headline number must not rest
+    # on the solver grading itself -- A*X - B is recomputed from the downloaded X with the stand-alone multiply
+    from tfqmrgpu_amd.fd_generator import FDExample
+    pr = FDExample(16, 120, 4, 2, -0.25, 4).problem()
+    assert (pr.mb, pr.nnzbA, pr.nnzbX, pr.nnzbB, pr.LM, pr.LN) == (3573, 17589, 138229, 49, 16, 16)
+    st, X, info = T.solve_problem(pr, "z", threshold=1e-9, max_iterations=2000)
+    assert st == 0 and info["residual"] <= 1e-9 and 10 <= info["iterations"] <= 20
+    _check_solution_on_device(torch_cuda, oracle, pr, "z", X, info, 1e-9)
+    # the same system in the reference CPU path's shadow-vector mode converges to the same solution
+    st2, X2, info2 = T.solve_problem(pr, "z", threshold=1e-9, max_iterations=2000, shadow_mode=T.SHADOW_GLIBC_RAND)
+    assert st2 == 0 and np.abs(X2 - X).max() <= 1e-7 * np.abs(X).max()
+
+
 def test_config3_small_against_the_oracle(oracle):
     # the generator of BASELINE config 3 (13-point block stencil, 32x32 complex<float>, 2 block columns = 64 RHS) at 8 x 8 rows
     pr = PR.stencil_2d(8, 8, 32, 32, 2, seed=3, points=13)

@@ -107,6 +107,7 @@ class FDExample:
         # A: for every row the stencil blocks that land on an existing row, in stencil order (:664-694)
         coords = np.stack([row_keys & 0xFF, (row_keys >> 8) & 0xFF, (row_keys >> 16) & 0xFF], axis=1)
         signed = np.where(coords > 127, coords - 256, coords)
+        self.row_xyz = signed                             # block coordinates of every row (probes of the row order use them)
         ob = np.array(origin, dtype=np.int64)
         nk = ((signed[:, None, 0] + ob[None, :, 0]) & 0xFF) | (((signed[:, None, 1] + ob[None, :, 1]) & 0xFF) << 8) \
             | (((signed[:, None, 2] + ob[None, :, 2]) & 0xFF) << 16)
