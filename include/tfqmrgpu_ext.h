@@ -98,11 +98,7 @@ tfqmrgpuStatus_t tfqmrgpuExt_getWorkVector(tfqmrgpuHandle_t handle, tfqmrgpuBsrs
  * All pointers are DEVICE pointers.  Blocks are in the native layout RRRRIIII:
  * A[nnzbA][2][lm(k)][lm(i)] (transposed), X|Y[nnzb][2][lm][ln].
  * Same contract as the reference kernel gemmNxNf (tfqmrgpu_blockmult.hxx:9-93).
- * Accuracy note: for complex<double> blocks larger than 16 x 16 the kernels form a complex product from THREE real
- * products (P1 = Re A Re X, P2 = Im A Im X, P3 = (Re A + Im A)(Re X + Im X); Re = P1 - P2, Im = P3 - P1 - P2): the error of
- * both components is bounded relative to |A| |X| (k eps |A||X| for k accumulated terms), not relative to the component itself --
- * an imaginary part that is 10^-k times smaller than the real part keeps k digits fewer than with four products.
- * TFQMRGPU_3M=0 in the environment selects four products everywhere (tests/test_gpu_parity.py::test_three_product_form_error_bound). */
+ * Four real products per complex one, as the reference (the three-product form is an option of a PLAN, section 6). */
 tfqmrgpuStatus_t tfqmrgpuExt_multiply(tfqmrgpuHandle_t handle,
     char precision, int lm, int ln,
     uint32_t nnzbY, uint32_t const *starts_d, uint32_t const *pairs_d,
@@ -112,7 +108,8 @@ tfqmrgpuStatus_t tfqmrgpuExt_multiply(tfqmrgpuHandle_t handle,
  * plan's X (setMatrix('X') before, getMatrix('X') afterwards), truncated to the pattern of X like every product of the
  * solver.  Uses the multiply kernel and the block / element order of the solver itself -- for 16 x 16
  * complex<double> plans the row-pair-interleaved one -- so it is also what bench.py times as "the BSR multiply".
- * `repetitions` > 1 computes the product that many times from the same X (timing); asynchronous on the handle's stream. */
+ * `repetitions` > 1 computes the product that many times from the same X (timing); `repetitions` < 0: that many launches and NO copy
+ * of the product back into X (a timed region then holds the multiply kernel alone); asynchronous on the handle's stream. */
 tfqmrgpuStatus_t tfqmrgpuExt_applyOperator(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, int repetitions);
 
 /* ---- (4) multi-GPU: one process per GPU, block columns of X/B sharded ------------------- */
@@ -146,6 +143,22 @@ tfqmrgpuStatus_t tfqmrgpuExt_commDestroy(tfqmrgpuHandle_t handle);
  * (used by the CPU/gloo tests of the sharding logic and by MPI-based callers). */
 typedef void (*tfqmrgpuReduceMax_t)(void *ctx, double *values, int n);
 tfqmrgpuStatus_t tfqmrgpuExt_setReduceCallback(tfqmrgpuHandle_t handle, tfqmrgpuReduceMax_t fn, void *ctx);
+
+/* ---- (6) precision options -------------------------------------------------------------- */
+/* Mixed precision: tfqmrgpu_bsrsv_bufferSize(..., 'm', ...) -- dormant in the reference (tfqmrgpu.cu:42, "load float, multiply-
+ * accumulate double, store float"; tfqmrgpu.h:72 "start with float and converge double"), built here as iterative refinement:
+ * x, B and A are kept in double, every cycle computes r = b - A x in double, solves A d = r with the complex<float> tfQMR and adds
+ * d to x in double.  setMatrix / getMatrix of such a plan accept 'c' AND 'z' data (converted on the way); solve's threshold is
+ * max_rhs |b - A x| / |b| in double arithmetic, maxIterations bounds the sum of the float iterations; getInfo reports that sum.
+ * The buffer is 11 float-sized vectors against 15 for 'z'.  Where float iterations cannot reduce the residual (systems on which
+ * the 'c' solver stagnates above ~0.1) solve returns TFQMRGPU_STATUS_MAX_ITERATIONS with the best x.
+ * getRefinementHistory: the relative residual (double arithmetic) in front of every float solve and at the end; returns the count. */
+int32_t tfqmrgpuExt_getRefinementHistory(tfqmrgpuBsrsvPlan_t plan, double *residual, int32_t capacity);
+/* Three real products per complex one (Gauss) in the complex<double> multiplies of the block shapes above 16 x 16: a quarter fewer
+ * matrix instructions (64 x 64: iteration -7 %), but Im = P3 - P1 - P2 is accurate relative to |A||X| only -- an imaginary part
+ * 10^-k times smaller than the real part loses k digits against the reference's four products.  OFF unless switched on here
+ * (it was the default until round 2); call before solve. */
+tfqmrgpuStatus_t tfqmrgpuExt_setThreeProductMultiply(tfqmrgpuBsrsvPlan_t plan, int on);
 
 /* ---- (5) user-defined linear operator --------------------------------------------------- */
 /* The reference lets C++ users replace the block-sparse operator by their own `action_t` class whose

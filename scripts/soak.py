@@ -14,16 +14,17 @@ s = T.Solver()
 s.create_plan(pr)
 s.set_buffer(nbytes=s.buffer_size(pr.LM, pr.LN, prec))
 s.set_matrix("A", pr.A); s.set_matrix("B", pr.B)
-seen = {}
+seen, digests = {}, set()
 for i in range(N):
     st = s.solve(pr.tolerance, 2000)
     info = s.get_info()
     key = (st, info["iterations"], info["residual"])
     if i % 10 == 0 or key not in seen:
         X = s.get_matrix()
-        key = key + (hashlib.md5(np.ascontiguousarray(X).tobytes()).hexdigest(),)
-    seen.setdefault(key[:3], []).append(i)
+        digests.add(hashlib.md5(np.ascontiguousarray(X).tobytes()).hexdigest())     # the solution BITS of every sampled solve
+    seen.setdefault(key, []).append(i)
     if i % 20 == 0:
-        print(i, key, flush=True)
-print("%s: %d solves, distinct (status, iterations, residual): %d" % (name, N, len(seen)))
+        print(i, key, sorted(digests), flush=True)
+print("%s: %d solves, distinct (status, iterations, residual): %d, distinct md5 of the sampled solutions: %d" % (name, N, len(seen), len(digests)))
 assert len(seen) == 1, seen
+assert len(digests) == 1, digests

@@ -1,6 +1,7 @@
-"""Worker of tests/test_gpu_switches.py: solves one fixture with the PRODUCT in a fresh process, so that the library
-reads the tuning switches of THIS process' environment (they are read once per process), and writes status,
-iterations, residual, bound history and solution to argv[1].
+"""Worker of tests/test_gpu_hash_mode.py: solves one fixture in a fresh process and writes status, iterations, residual, bound history
+and solution to argv[1].  With TFQMRGPU_* tuning switches in the environment the LAB build of the library is loaded
+(libtfQMRgpu_lab.so: the same sources compiled with -DTFQ_LAB, tfq_switch.hpp -- the product has its switches frozen and reads
+nothing from the environment); without, the product.
 argv: out.npz fixture precision threshold [shape for `stencil:` fixtures]"""
 import os
 import sys
@@ -25,7 +26,11 @@ def main():
     out, name, prec, tol = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
     import torch
     assert torch.cuda.is_available(), "no GPU: the product has no CPU fallback"
+    switches = [k for k in os.environ if k.startswith("TFQMRGPU_") and k != "TFQMRGPU_LIB"]
+    if switches and "TFQMRGPU_LIB" not in os.environ:
+        os.environ["TFQMRGPU_LIB"] = os.path.join(ROOT, "tfqmrgpu_amd", "lib", "libtfQMRgpu_lab.so")
     import tfqmrgpu_amd as T
+    assert os.path.basename(T.LIB_PATH) == ("libtfQMRgpu_lab.so" if switches else "libtfQMRgpu.so"), T.LIB_PATH
     st, X, info = T.solve_problem(problem(name), prec, threshold=tol, max_iterations=300)
     np.savez(out, status=st, iterations=info["iterations"], residual=info["residual"], history=info["bound_history"], X=X)
 

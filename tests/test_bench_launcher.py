@@ -45,8 +45,31 @@ def test_two_ranks_when_two_gpus_are_visible():
     assert two["n_gpus"] == 2 and two["solve_status"] == 0 and "2 ranks" in two["config"]["reduce_path"]
 
 
-def test_config4_shard_through_the_launcher():
-    # BASELINE config 4 (256 block columns split over the ranks; strong scaling) with one rank would need 130 GB: the
-    # workload only has to be accepted and described here, its 32-column shard runs in tests/test_gpu_configs.py
+def test_unknown_workload_is_refused():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "nonsense"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "unknown workload" in (r.stdout + r.stderr)
+
+
+def test_config4_workload_builds_only_the_ranks_shard():
+    """BASELINE config 4 through bench.py's own build_problem (`--workload cfg4[:nx:ncols]`, strong scaling: the block columns of ONE
+    system split over the ranks with tfqmrgpuExt_shardColumns) at a reduced grid: every rank gets a contiguous range of block columns,
+    the ranges tile the whole, and a rank's solve gives the bits the unsharded solve has for its columns."""
+    import numpy as np
+    import tfqmrgpu_amd as T
+    sys.path.insert(0, ROOT)
+    from bench import build_problem
+    full, prec, _ = build_problem("cfg4:12:16", 0, 1)
+    assert prec == "z" and (full.first_col, full.n_cols) == (0, 16)
+    st, X, info = T.solve_problem(full, "z", threshold=1e-9, max_iterations=200)
+    assert st == 0
+    col_of = full.colIndX
+    at = 0
+    for rank in range(3):
+        pr, _, desc = build_problem("cfg4:12:16", rank, 3)
+        assert pr.first_col == at and "split over 3 GPUs" in desc
+        at += pr.n_cols
+        stp, Xp, ip = T.solve_problem(pr, "z", threshold=1e-9, max_iterations=200)
+        mine = (col_of >= pr.first_col) & (col_of < pr.first_col + pr.n_cols)
+        assert stp == 0 and Xp.shape[0] == mine.sum()
+        assert np.abs(Xp - X[mine]).max() <= 1e-7 * np.abs(X).max()      # (its own stopping test: the same solution, not the same iteration)
+    assert at == 16

@@ -120,7 +120,7 @@ def test_recomputing_the_shadow_vector_changes_no_bit(tmp_path, name, prec, tol)
     assert np.array_equal(a["X"], b["X"])
 
 
-SWITCHES = [dict(TFQMRGPU_3M=0), dict(TFQMRGPU_3M=2), dict(TFQMRGPU_EPI_PREFETCH=0), dict(TFQMRGPU_ORDER=0),
+SWITCHES = [dict(TFQMRGPU_3M=1), dict(TFQMRGPU_3M=2), dict(TFQMRGPU_EPI_PREFETCH=0), dict(TFQMRGPU_ORDER=0),
             dict(TFQMRGPU_DEPTH=1), dict(TFQMRGPU_DEPTH=4), dict(TFQMRGPU_CHUNK_KIB=64), dict(TFQMRGPU_ORDER_G=8),
             dict(TFQMRGPU_ILV=0),     # ILV=0: 16 x 16 and 8 x 8 z plans keep the native element order (k_spmm_mfma / k_spmm_mfma8)
             dict(TFQMRGPU_A_STREAM=0), dict(TFQMRGPU_CLAMP=0)]
@@ -129,9 +129,12 @@ SWITCHES = [dict(TFQMRGPU_3M=0), dict(TFQMRGPU_3M=2), dict(TFQMRGPU_EPI_PREFETCH
 @pytest.mark.parametrize("name,prec,tol", [("stencil:16:16:16:16:4:7:5", "z", 1e-9), ("stencil:8:8:32:32:2:3:13", "z", 1e-9),
                                            ("stencil:12:12:8:8:4:5:5", "z", 1e-9), ("stencil:12:12:16:16:1:7:5", "z", 1e-9)])   # one block column: A streamed past the caches
 def test_tuning_switches_change_code_paths_not_results(tmp_path, name, prec, tol):
-    """every non-default value of the environment switches: same status and iteration count, the
-    solution within rounding (a switch may change the order of a sum: chunk length, three-product form)"""
+    """every non-default value of the tuning switches (read by the LAB build only, the product has them frozen):
+    same status and iteration count, the solution within rounding (a switch may change the order of a sum: chunk length,
+    three-product form).  The base line is the PRODUCT, so the lab build with every switch at its default is checked against it too."""
     base = _worker(tmp_path, "default", name, prec, tol)
+    lab = _worker(tmp_path, "lab_default", name, prec, tol, TFQMRGPU_DEPTH=0)      # (0 = default) loads the lab build
+    assert np.array_equal(lab["X"], base["X"]) and np.array_equal(lab["history"], base["history"])
     assert int(base["status"]) == 0
     for n, sw in enumerate(SWITCHES):
         got = _worker(tmp_path, "sw%d" % n, name, prec, tol, **sw)

@@ -33,35 +33,7 @@ def _tol(prec):
     return 1e-7 if prec == "z" else 1e-3
 
 
-# Rounding differences (MFMA summation order, FMA contraction, other reduction order) are amplified by the tfQMR
-# recurrences; how fast depends on the conditioning.  The tolerances below are 2 x the deviation OBSERVED on MI355X
-# against the oracle with the same (glibc) shadow vector (tests/parity_report.py -> profiles/r02_parity_report.txt; the
-# largest of the values seen with the arithmetic variants the library has had: round-1 and round-2 multiply kernels,
-# compiler-contracted and explicit fused multiply-adds),
-# per fixture: hist = whole per-iteration bound history (relative), half = its first half, res = final residual
-# (relative).  The north star's "residuals matching to 1e-6 relative" holds on every fixture whose final residual sits
-# at the threshold (1e-10 .. 1e-9: the 16x16 FD systems that bench.py times, the stencils, the dense system); where the
-# solve ends in rounding noise (julia_kat: 5e-15; 3-D Poisson at energy 0, fd_8x8_3d: the last iterations shed 8 digits
-# per step) or the blocks are 4x4 (longer sums in another order) the END of the trajectory differs more and the table
-# says by how much; the first half of the history agrees to 1e-7 everywhere.
-Z_TOL = {
-    "fd_16x16_2d":       dict(hist=3e-10, half=4e-11, res=3e-7),    # observed 1.3e-10 / 2.0e-11 / 1.1e-7
-    "fd_16x16_small":    dict(hist=3e-10, half=3e-11, res=3e-7),    # 1.4e-10 / 1.1e-11 / 1.4e-7
-    "dense_random":      dict(hist=3e-10, half=2e-12, res=5e-6),    # 1.1e-10 / 6.8e-13 / 2.3e-6
-    "stencil_8x8":       dict(hist=1e-11, half=1e-12, res=2e-6),    # 9.5e-13 / 1.7e-13 / 1.0e-6
-    "stencil_8x32":      dict(hist=1e-10, half=1e-12, res=3e-7),    # 4.3e-11 / 2.6e-13 / 1.3e-7
-    "dense_random_rect": dict(hist=1e-10, half=1e-12, res=8e-6),    # 4.5e-11 / 2.4e-13 / 3.7e-6 (residual 2e-11: noise floor)
-    "fd_4x4_2d":         dict(hist=2e-5,  half=1e-10, res=8e-5),    # 9.2e-6  / 2.0e-11 / 3.8e-5
-    "fd_8x8_3d":         dict(hist=1.7,   half=1.4e-7, res=0.52),   # 8.5e-1  / 7.0e-8  / 2.6e-1 (both below the threshold)
-    "julia_kat":         dict(hist=1.3,   half=1e-14, res=0.5),     # 6.5e-1  / 2.2e-15 / 2.4e-1 (converges to 5e-15)
-}
-# complex<float>: the trajectories separate after a few iterations (every product is rounded to 24 bits in another order).
-# it = allowed difference of the iteration count, x = max|X - X0| / max|X0|; observed: equal counts everywhere but on the
-# 3-D Poisson fixture at its float floor (tol 1e-2: 26 against 21 iterations, both converged, X within 0.6 * tol).
-C_TOL = {
-    "fd_8x8_3d": dict(it=10, x=1.2e-2), "fd_16x16_2d": dict(it=0, x=1.1e-4), "fd_16x16_small": dict(it=0, x=2.2e-4),
-    "julia_kat": dict(it=0, x=4e-6), "dense_random": dict(it=0, x=6e-7), "stencil_8x8": dict(it=0, x=4e-7),
-}
+from tolerances import C_TOL, Z_TOL  # noqa: E402  (shared with tests/test_oracle_sensitivity.py, which runs without a GPU)
 
 
 @pytest.mark.parametrize("name", ALL_NAMES)
@@ -560,10 +532,11 @@ def test_apply_operator_on_plan_data(oracle, prec, shape):
     assert np.abs(got - want).max() <= eps * LM * 6 * max(1.0, np.abs(want).max())
 
 
-def test_three_product_form_error_bound(torch_cuda, oracle):
-    """32 x 32 complex<double> uses three real products per complex one (TFQMRGPU_3M): with imaginary
-    parts 1e-8 times smaller than the real parts the result is accurate relative to |A||X| (a few eps per accumulated term),
-    i.e. the imaginary part loses about 8 digits against the oracle's four-product sum -- the documented bound, not more"""
+def test_three_product_form_is_opt_in(torch_cuda, oracle):
+    """32 x 32 complex<double>: the default multiply forms a complex product from four real ones like the reference, so an
+    imaginary part 1e-8 times smaller than the real part keeps its digits (up to r02 the three-product form was the default and lost 8
+    of them).  With tfqmrgpuExt_setThreeProductMultiply the plan's multiplies use three products: accurate relative to |A||X| (a few
+    eps per accumulated term), i.e. the imaginary part may lose the 8 digits -- the documented bound, not more."""
     torch = torch_cuda
     LM = LN = 32
     rng = np.random.default_rng(77)
@@ -583,9 +556,30 @@ def test_three_product_form_error_bound(torch_cuda, oracle):
     scale = 6 * LM * 1.0                                  # |A||X| summed over at most 6 products of 32 terms, entries <= 1
     eps = np.finfo(np.float64).eps
     assert np.abs(got[:, 0] - want[:, 0]).max() <= 8 * eps * scale
-    assert np.abs(got[:, 1] - want[:, 1]).max() <= 8 * eps * scale      # absolute: the same bound as the real part ...
-    rel_im = np.abs(got[:, 1] - want[:, 1]).max() / np.abs(want[:, 1]).max()
-    assert rel_im <= 8 * eps * scale / 1e-8                               # ... i.e. up to 1e8 times eps relative to Im itself
+    assert np.abs(got[:, 1] - want[:, 1]).max() <= 16 * eps * scale * 1e-8     # four products: Im accurate relative to ITSELF
+
+    # the option, on a plan: same system solved with and without it
+    pr = PR.stencil_2d(8, 8, 32, 32, 2, seed=3, points=13)
+    pr.A = pr.A.real + 1e-8j * pr.A.imag                                       # imaginary parts 1e-8 of the real parts
+    res = {}
+    xin = rng.uniform(-1, 1, (pr.nnzbX, LM, LN)) + 1e-8j * rng.uniform(-1, 1, (pr.nnzbX, LM, LN))
+    for on in (False, True):
+        with T.Solver() as s:
+            s.create_plan(pr)
+            s.set_buffer(nbytes=s.buffer_size(LM, LN, "z"))
+            s.set_three_product_multiply(on)
+            s.set_matrix("A", pr.A)
+            s.set_matrix("X", xin)
+            s.apply_operator()
+            res[on] = s.get_matrix()
+    ref = res[False]
+    assert np.abs(res[True].real - ref.real).max() <= 64 * eps * 13 * LM * np.abs(ref.real).max()
+    d_im = np.abs(res[True].imag - ref.imag).max()
+    assert 0 < d_im <= 64 * eps * 13 * LM * np.abs(ref.real).max()             # differs (it IS another formula), within eps |A||X|
+    st0, X0, i0 = T.solve_problem(pr, "z", threshold=1e-9, max_iterations=100)
+    st1, X1, i1 = T.solve_problem(pr, "z", threshold=1e-9, max_iterations=100, three_products=True)
+    assert st0 == st1 == 0 and i0["iterations"] == i1["iterations"]
+    assert np.abs(X1 - X0).max() <= 1e-9 * np.abs(X0).max()
 
 
 def test_profile_keeps_the_first_iteration_apart():

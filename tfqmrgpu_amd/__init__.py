@@ -16,6 +16,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TFQMRGPU_LIB", os.path.join(_HERE, "lib", "libtfQMRgpu.so"))   # override for A/B builds
+LAB_LIB_PATH = os.path.join(_HERE, "lib", "libtfQMRgpu_lab.so")   # the same sources with -DTFQ_LAB: reads the TFQMRGPU_* tuning switches
 
 LAYOUT_RRRRIIII, LAYOUT_RRIIRRII, LAYOUT_RIRIRIRI = 0x0F, 0x33, 0x55
 SHADOW_HASH, SHADOW_GLIBC_RAND = 0, 1
@@ -36,6 +37,7 @@ EXT_SYMBOLS = [  # include/tfqmrgpu_ext.h
     "tfqmrgpuExt_setShadowVector", "tfqmrgpuExt_getShadowVector", "tfqmrgpuExt_getWorkVector", "tfqmrgpuExt_multiply", "tfqmrgpuExt_applyOperator", "tfqmrgpuExt_shardColumns",
     "tfqmrgpuExt_freeShard", "tfqmrgpuExt_commUniqueId", "tfqmrgpuExt_commInit",
     "tfqmrgpuExt_commDestroy", "tfqmrgpuExt_setReduceCallback", "tfqmrgpuExt_setOperator",
+    "tfqmrgpuExt_getRefinementHistory", "tfqmrgpuExt_setThreeProductMultiply",
 ]
 FORTRAN_SYMBOLS = [  # tfqmrgpu_amd/csrc/tfq_fortran.c
     "tfqmrgpuprinterror_", "tfqmrgpucreatehandle_", "tfqmrgpudestroyhandle_", "tfqmrgpusetstream_",
@@ -127,6 +129,8 @@ def load_library(path=LIB_PATH):
     lib.tfqmrgpuExt_commDestroy.argtypes = [P]
     lib.tfqmrgpuExt_setReduceCallback.argtypes = [P, REDUCE_CB, P]
     lib.tfqmrgpuExt_setOperator.argtypes = [P, OPERATOR_CB, P]
+    lib.tfqmrgpuExt_getRefinementHistory.argtypes = [P, P, C.c_int32]
+    lib.tfqmrgpuExt_setThreeProductMultiply.argtypes = [P, I]
     return lib
 
 
@@ -222,6 +226,9 @@ class Solver:
         _check(lib.tfqmrgpu_bsrsv_bufferSize(self.handle, self.plan, LM, LM, LN, LN, precision.encode(), C.byref(n)),
                "tfqmrgpu_bsrsv_bufferSize")
         self.LM, self.LN, self.precision = LM, LN, precision
+        # precision of the host arrays handed to set_matrix / returned by get_matrix: the plan's, for a mixed-precision plan ('m',
+        # which takes both) double unless the caller sets data_precision = "c"
+        self.data_precision = "z" if precision in "zm" else "c"
         return n.value
 
     def set_shadow_mode(self, mode):
@@ -249,24 +256,24 @@ class Solver:
 
     # -- values ----------------------------------------------------------------------------------------
     def _real_dtype(self):
-        return np.float64 if self.precision == "z" else np.float32
+        return np.float64 if self.data_precision == "z" else np.float32
 
     def set_matrix(self, var, blocks, trans="n", layout=LAYOUT_RIRIRIRI):
         """blocks: complex array [nnzb, rows, cols] (interleaved layout) or a raw real array for other layouts"""
         a = np.asarray(blocks)
         if np.iscomplexobj(a):
-            a = np.ascontiguousarray(a.astype(np.complex128 if self.precision == "z" else np.complex64))
+            a = np.ascontiguousarray(a.astype(np.complex128 if self.data_precision == "z" else np.complex64))
         else:
             a = np.ascontiguousarray(a, dtype=self._real_dtype())
         self._keep.append(a)
-        st = lib.tfqmrgpu_bsrsv_setMatrix(self.handle, self.plan, var.encode(), _ptr(a), self.precision.encode(),
+        st = lib.tfqmrgpu_bsrsv_setMatrix(self.handle, self.plan, var.encode(), _ptr(a), self.data_precision.encode(),
                                           self.LN if var in "XBxb" else self.LM, self.LM, trans.encode(), layout)
         return _check(st, "tfqmrgpu_bsrsv_setMatrix('%s')" % var)
 
     def get_matrix(self, nnzb=None, trans="n", layout=LAYOUT_RIRIRIRI, raw=False):
         nnzb = self.problem.nnzbX if nnzb is None else nnzb
         out = np.zeros((nnzb, self.LM, self.LN, 2), dtype=self._real_dtype())
-        st = lib.tfqmrgpu_bsrsv_getMatrix(self.handle, self.plan, b"X", _ptr(out), self.precision.encode(),
+        st = lib.tfqmrgpu_bsrsv_getMatrix(self.handle, self.plan, b"X", _ptr(out), self.data_precision.encode(),
                                           self.LN, self.LM, trans.encode(), layout)
         _check(st, "tfqmrgpu_bsrsv_getMatrix")
         if raw or layout != LAYOUT_RIRIRIRI:
@@ -306,6 +313,17 @@ class Solver:
         _check(lib.tfqmrgpu_bsrsv_getInfo(self.handle, self.plan, C.byref(r), C.byref(it), C.byref(f), C.byref(fa)),
                "tfqmrgpu_bsrsv_getInfo")
         return dict(residual=r.value, iterations=it.value, flops=f.value, flops_all=fa.value)
+
+    def refinement_history(self):
+        """mixed precision: relative residual (double arithmetic) in front of every float solve and at the end"""
+        n = lib.tfqmrgpuExt_getRefinementHistory(self.plan, None, 0)
+        h = np.zeros(max(n, 0), dtype=np.float64)
+        if n > 0:
+            lib.tfqmrgpuExt_getRefinementHistory(self.plan, _ptr(h), n)
+        return h
+
+    def set_three_product_multiply(self, on=True):
+        _check(lib.tfqmrgpuExt_setThreeProductMultiply(self.plan, int(on)), "tfqmrgpuExt_setThreeProductMultiply")
 
     def bound_history(self):
         n = lib.tfqmrgpuExt_getBoundHistory(self.plan, None, 0)
@@ -365,11 +383,16 @@ def hash_shadow_vector(pr):
     return v.reshape(pr.nnzbX, 2, pr.LM, pr.LN)
 
 
-def solve_problem(pr, precision="z", threshold=None, max_iterations=2000, transA="n", shadow_mode=SHADOW_HASH, stream=None):
+def solve_problem(pr, precision="z", threshold=None, max_iterations=2000, transA="n", shadow_mode=SHADOW_HASH, stream=None,
+                  data_precision=None, three_products=False):
     """createPlan .. getMatrix in one go; returns (status, X[nnzbX, LM, LN] complex, info dict)."""
     with Solver(stream) as s:
         s.create_plan(pr)
         nbytes = s.buffer_size(pr.LM, pr.LN, precision)
+        if data_precision:
+            s.data_precision = data_precision
+        if three_products:
+            s.set_three_product_multiply(True)
         s.set_shadow_mode(shadow_mode)
         s.set_buffer(nbytes=nbytes)
         s.set_matrix("A", pr.A, transA)
@@ -377,6 +400,7 @@ def solve_problem(pr, precision="z", threshold=None, max_iterations=2000, transA
         status = s.solve(pr.tolerance if threshold is None else threshold, max_iterations)
         info = s.get_info()
         info["bound_history"] = s.bound_history()
+        info["refinement_history"] = s.refinement_history()
         info["buffer_bytes"] = nbytes
         X = s.get_matrix()
     return status, X, info

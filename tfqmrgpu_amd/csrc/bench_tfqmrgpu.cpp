@@ -24,6 +24,7 @@
 #include <cmath>
 #include <complex>
 #include <cstdint>
+#include <csignal>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -480,8 +481,16 @@ int bench_tfqmr(int argc, char** argv) {
         if (0 == pid) { int const rc = tfqmr_rank(path, prec, maxiter, r, gpus, tmp); std::fflush(nullptr); _exit(rc); }
         kids.push_back(pid);
     }
+    // the first rank that ends with an error takes the others with it: they would wait for ever in a collective it never joins
     int worst = 0;
-    for (auto pid : kids) { int status = 0; waitpid(pid, &status, 0); worst = std::max(worst, WIFEXITED(status) ? WEXITSTATUS(status) : 128); }
+    for (size_t left = kids.size(); left > 0; --left) {
+        int status = 0;
+        pid_t const pid = waitpid(-1, &status, 0);
+        if (pid < 0) break;
+        int const rc = WIFEXITED(status) ? WEXITSTATUS(status) : 128;
+        if (rc != 0 && 0 == worst) for (auto k : kids) if (k != pid) kill(k, SIGTERM);
+        worst = std::max(worst, rc);
+    }
     double flops = 0, tmax = 0; int its = 0;
     for (int r = 0; r < gpus; ++r) {
         std::ifstream f(tmp + "/rank" + std::to_string(r));

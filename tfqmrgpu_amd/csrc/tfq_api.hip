@@ -12,6 +12,7 @@
 
 #include "tfq_device.hpp"
 #include "tfq_vec.hpp"
+#include "tfq_switch.hpp"
 
 using namespace tfq;
 
@@ -26,11 +27,13 @@ DevPlan resolve(Plan const& p) {
     d.LM = p.LM; d.LN = p.LN; d.dbl = ('z' == p.precision);
     d.nCols = p.nCols; d.nnzbX = p.nnzbX; d.nnzbB = p.nnzbB; d.nnzbA = p.nnzbA;
     d.nChunks = uint32_t(p.chunks.col.size());
-    static int const hashEnv = [] { auto v = std::getenv("TFQMRGPU_HASHV3"); return v ? std::atoi(v) : 1; }();
-    d.hashV3 = (p.v3IsHash && hashEnv) ? 1 : 0;   // TFQMRGPU_HASHV3=0: the multiply kernels read v3 also in hash mode
+    static int const hashEnv = lab_switch("TFQMRGPU_HASHV3", 1);
+    d.hashV3 = (p.v3IsHash && hashEnv) ? 1 : 0;   // (lab builds, TFQMRGPU_HASHV3=0: the multiply kernels read v3 also in hash mode)
     d.ilv = p.ilv;
-    static int const antEnv = [] { auto v = std::getenv("TFQMRGPU_A_STREAM"); return v ? std::atoi(v) : 1; }();
-    d.aOnce = (p.aOnce && antEnv) ? 1 : 0;   // TFQMRGPU_A_STREAM=0: A operands always through the caches
+    static int const antEnv = lab_switch("TFQMRGPU_A_STREAM", 1);
+    d.aOnce = (p.aOnce && antEnv) ? 1 : 0;   // (lab builds, TFQMRGPU_A_STREAM=0: A operands always through the caches)
+    d.m3 = p.threeProducts ? 1 : 0;
+    d.R = ('m' == p.precision) ? at(p.wR) : nullptr;
     d.x = at(p.wX); d.v4 = at(p.wV4); d.v5 = at(p.wV5); d.v6 = at(p.wV6); d.v7 = at(p.wV7);
     d.v8 = at(p.wV8); d.v9 = at(p.wV9); d.B = at(p.wB); d.A = at(p.wA); d.v3 = (float*)at(p.wV3);
     d.rho = at(p.wRho); d.alfa = at(p.wAlfa); d.beta = at(p.wBeta); d.c67 = at(p.wC67); d.eta = at(p.wEta);
@@ -43,6 +46,16 @@ DevPlan resolve(Plan const& p) {
     d.order = (uint32_t*)at(p.wOrder); d.bOfX = (uint32_t*)at(p.wBofX); d.starts = (uint32_t*)at(p.wStarts); d.pairs = (uint32_t*)at(p.wPairs);
     d.subset = (uint32_t*)at(p.wSubset); d.bColPtr = (uint32_t*)at(p.wBColPtr); d.bList = (uint32_t*)at(p.wBList);
     d.u2i = (uint32_t*)at(p.wU2I); d.rowI = (uint32_t*)at(p.wRowI); d.origCol = (int32_t*)at(p.wOrigCol);
+    return d;
+}
+
+// mixed precision: the double-precision side of the plan as a plan of its own (x, B, A in double, element order ilvZ, the chunk
+// tables of the float plan) -- what the layout conversions and the refinement's multiply work on
+static DevPlan resolveZ(Plan const& p) {
+    DevPlan d = resolve(p);
+    char* b = p.buffer;
+    d.dbl = true; d.ilv = p.ilvZ; d.hashV3 = 0; d.R = nullptr;
+    d.x = b + p.wXz.offset; d.B = b + p.wBz.offset; d.A = b + p.wAz.offset;
     return d;
 }
 
@@ -81,12 +94,16 @@ static Stage stage_of(Plan const& p) {
     return { p.buffer + p.wV4.offset, (p.wV9.offset + p.wV9.bytes) - p.wV4.offset };
 }
 
-// move blocks between a host array in the caller's layout and a native device array
-static tfqmrgpuStatus_t transfer_blocks(Plan& p, hipStream_t s, int direction, bool dbl, void* native,
-    void* host, uint32_t const* u2n, uint32_t nBlocks, int nR, int nC, int layout, bool trans, bool conj, Stage const* own = nullptr)
+// move blocks between a host array in the caller's layout and a native device array.  userDbl: precision of the caller's array,
+// nativeDbl / ilv: precision and element order of the library's; `also`: a second library-side copy of the same blocks (the float A of a
+// mixed-precision plan next to its double A)
+struct Target { void* native; bool dbl; int ilv; };
+static tfqmrgpuStatus_t transfer_blocks(Plan& p, hipStream_t s, int direction, bool userDbl, Target const& to,
+    void* host, uint32_t const* u2n, uint32_t nBlocks, int nR, int nC, int layout, bool trans, bool conj, Stage const* own = nullptr,
+    Target const* also = nullptr)
 {
     Stage const st = own ? *own : stage_of(p);
-    size_t const blockBytes = size_t(2) * nR * nC * (dbl ? 8 : 4);
+    size_t const blockBytes = size_t(2) * nR * nC * (userDbl ? 8 : 4);
     size_t const cap = st.bytes / blockBytes;
     if (cap < 1) return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED);
     for (uint32_t first = 0; first < nBlocks; ) {
@@ -94,9 +111,10 @@ static tfqmrgpuStatus_t transfer_blocks(Plan& p, hipStream_t s, int direction, b
         char* h = (char*)host + size_t(first) * blockBytes;
         if (0 == direction) {
             TFQ_HIP(hipMemcpyAsync(st.ptr, h, n * blockBytes, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
-            launch_convert(0, dbl, native, st.ptr, u2n, first, n, nR, nC, layout, trans, conj, p.ilv, s);
+            launch_convert(0, userDbl, to.dbl, to.native, st.ptr, u2n, first, n, nR, nC, layout, trans, conj, to.ilv, s);
+            if (also) launch_convert(0, userDbl, also->dbl, also->native, st.ptr, u2n, first, n, nR, nC, layout, trans, conj, also->ilv, s);
         } else {
-            launch_convert(1, dbl, native, st.ptr, u2n, first, n, nR, nC, layout, trans, conj, p.ilv, s);
+            launch_convert(1, userDbl, to.dbl, to.native, st.ptr, u2n, first, n, nR, nC, layout, trans, conj, to.ilv, s);
             TFQ_HIP(hipMemcpyAsync(h, st.ptr, n * blockBytes, hipMemcpyDeviceToHost, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
         }
         // the stage is reused by the next batch and the host array belongs to the caller
@@ -198,7 +216,11 @@ static Roctx const& roctx() { static Roctx const r; return r; }
 // and reads the control block of iteration `it` (copied to pinned memory behind it) before it
 // enqueues iteration it+DEPTH.  Iterations enqueued after the solve has stopped cost a few empty
 // launches.  Every rank enqueues the same number of iterations, so collectives always match.
-static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
+// `d`: the plan's device pointers (d.R set: the right-hand side is the X-shaped vector R and the per-RHS scalars have been set up
+// by the refinement, tfq_vec.hip); `early`: a refusal the caller has found already (it still has to travel through the ranks' vote);
+// every bound of the history is multiplied by histScale (a refinement cycle's bounds are relative to ITS right-hand side).
+struct SolveOutcome { Ctl last; double userFlops = 0; };
+static tfqmrgpuStatus_t run_tfqmr(Handle& h, Plan& p, DevPlan const& d, double tol, int maxIt, tfqmrgpuStatus_t early, double histScale, SolveOutcome& out) {
     hipStream_t const s = (hipStream_t)h.stream;
     bool const multi = (h.comm != nullptr) || (h.reduceFn != nullptr);
     constexpr int DEPTH = Plan::kDepth;
@@ -207,18 +229,16 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
     // launches, and enqueuing a slot (~50 us) is never slower than executing one (>= 60 us even for tiny systems), so a
     // deeper queue only adds to the tail (measured: 4 -> 2 gains 8 % on the 2-iteration solves of config 3, 5 % on
     // 1000-block systems, 0.8 % on P2; 1 loses on small systems).  TFQMRGPU_DEPTH = 1..4 overrides.
-    static int const depthEnv = [] { auto v = std::getenv("TFQMRGPU_DEPTH"); return v ? std::atoi(v) : 0; }();
+    static int const depthEnv = lab_switch("TFQMRGPU_DEPTH", 0);
     int ahead = (depthEnv >= 1 && depthEnv <= DEPTH) ? depthEnv : 2;
 
-    // what this rank can tell before it touches the device
-    tfqmrgpuStatus_t early = TFQMRGPU_STATUS_SUCCESS;
-    if (!p.buffer) early = TFQ_ERR(TFQMRGPU_POINTER_INVALID);
-    else if ('z' != p.precision && 'c' != p.precision) early = err(TFQMRGPU_PRECISION_MISSMATCH, __LINE__ % 10000, p.precision);
     if (multi) {
         // One collective in front of every solve: {deepest queue any rank wants, some rank cannot start}.  Every rank must
         // enqueue the same number of slots (the collectives have to match), and a rank that returned here on its own would
         // leave its peers waiting in their first all-reduce for ever -- so the refusal travels through the same reduction.
-        if (!h.voteBuf) TFQ_HIP(hipMalloc((void**)&h.voteBuf, 4 * sizeof(double)), TFQMRGPU_STATUS_ALLOCATION_FAILED)
+        // (the buffer of the vote is allocated with the communicator / callback, tfqmrgpuExt_commInit: a rank that failed to
+        //  allocate it HERE would leave before the collective and its peers would wait for ever)
+        if (!h.voteBuf) return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED);
         double vote[2] = { double(ahead), early ? 1. : 0. };
         TFQ_HIP(hipMemcpyAsync(h.voteBuf, vote, sizeof vote, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
         if (auto const st = reduce_over_ranks(h, h.voteBuf, 2, s)) return st;
@@ -228,7 +248,6 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         if (!early && vote[1] > 0.) early = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);   // a peer cannot start: nobody does
     }
     if (early) return early;
-    DevPlan const d = resolve(p);
 
     // pinned ring + events live with the plan (hipHostMalloc / event creation cost more than a small solve)
     if (!p.ring) {
@@ -252,10 +271,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
     auto const timed = [prof](int k) { return 1 == prof || (2 == prof && (TFQMRGPU_PROF_SPMM_V4_DOT == k || TFQMRGPU_PROF_SPMM_V5_NRM_DOT == k)); };
     EventList pev;
     if (prof && !pev.create(size_t(DEPTH) * (NK + 1))) return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED);
-    for (int k = 0; k < NK; ++k) { p.profLaunches[k] = 0; p.profMs[k] = 0; p.profGatedLaunches[k] = 0; p.profGatedMs[k] = 0; p.profFirstLaunches[k] = 0; p.profFirstMs[k] = 0; }
 
-    p.boundHistory.clear();
-    p.iterations_needed = maxIt; p.flops_performed = 0;
     { RoctxRange const range(roctx(), "tfQMR preparation"); TFQ_HIP(vec_launch(VEC_SETUP, d, tol, maxIt, s), TFQMRGPU_STATUS_LAUNCH_FAILED) }
     RoctxRange const range(roctx(), "tfQMR iterations");
 
@@ -282,7 +298,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         char* const xu = p.opScratch; char* const yu = xu + up256(vecBytes);
         auto const i2u = (uint32_t const*)(yu + up256(vecBytes));
         auto const colU = (uint16_t const*)((char const*)i2u + up256(size_t(p.nnzbX) * 4));
-        launch_convert(1, d.dbl, (EPI_RESIDUAL == epi) ? d.x : d.v6, xu, d.u2i, 0, p.nnzbX, p.LM, p.LN,
+        launch_convert(1, d.dbl, d.dbl, (EPI_RESIDUAL == epi) ? d.x : d.v6, xu, d.u2i, 0, p.nnzbX, p.LM, p.LN,
                        TFQMRGPU_LAYOUT_RRRRIIII, false, false, p.ilv, s);
         double fl = 0;
         auto const st = userOp(p.opCtx, yu, xu, colU, p.nnzbX, p.nCols, p.LM, p.LN, p.precision, (tfqmrgpuStream_t)s, &fl);
@@ -293,7 +309,8 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
 
     // part 0: all kernels of one iteration slot (most of them gate themselves off); 1: without the probe; 2: probe only
     static double const kOne = 1.;
-    // the max-reduction of a slot; a rank that has failed marks the record, so that every rank stops at this slot
+    // the max-reduction of a slot; a rank that has failed marks the record, so that every rank stops at THAT slot (the failing rank
+    // goes on completing slots until then, see the loop below; a rank whose device is lost cannot, its peers then wait in RCCL)
     auto reduce = [&](int what) {
         if (fail && hipSuccess != hipMemcpyAsync(&d.ctl->red[3 * what + 2], &kOne, sizeof kOne, hipMemcpyHostToDevice, s)) return;
         auto const st = reduce_over_ranks(h, &d.ctl->red[3 * what], 3, s);
@@ -354,7 +371,7 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
                 enqueue(0, part, 0 == it);
                 if (hipSuccess != hipEventSynchronize(ev[0])) { fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED); break; }
                 last = ring[0];
-                if (1 == part) p.boundHistory.push_back(last.max_bound2);
+                if (1 == part) p.boundHistory.push_back(last.max_bound2 * histScale);
             }
             if (prof) for (int k = 0; k < NK; ++k) {
                 float ms = 0;
@@ -366,13 +383,16 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
         }
     } else
     while (enq < std::min(ahead, maxIt)) { enqueue(enq % DEPTH, 0, 0 == enq); ++enq; }   // slot n runs iteration n (or nothing)
-    while (seen < enq && !fail) {
+    // A rank that has failed on the way (fail != 0) does not leave on its own when there are peers: they have slots with
+    // collectives enqueued ahead, which it must match.  It keeps completing slots -- reduce() marks every one of its records -- until
+    // the control block shows state 4 (every rank stops at the slot whose reduction carried the mark) or the iterations run out.
+    while (seen < enq && (!fail || multi)) {
         int const slot = seen % DEPTH;
-        if (hipSuccess != hipEventSynchronize(ev[slot])) { fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED); break; }
+        if (hipSuccess != hipEventSynchronize(ev[slot])) { if (!fail) fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED); break; }   // the device is gone: nothing left to match
         int const nprobes_before = last.nprobes;
         last = ring[slot];
         ++seen;
-        p.boundHistory.push_back(last.max_bound2);
+        p.boundHistory.push_back(last.max_bound2 * histScale);
         if (prof) for (int k = 0; k < NK; ++k) {
             if (!timed(k)) continue;
             bool const gated = (TFQMRGPU_PROF_PROBE == k && last.nprobes == nprobes_before); // probe not requested
@@ -402,12 +422,91 @@ static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
     if (hipSuccess != hipGetLastError() && !fail) fail = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
     if (fail) return fail;
     if (4 == last.state) return TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);   // another rank reported a failure; all ranks stopped at the same slot
+    out.last = last; out.userFlops = userFlops;
+    return TFQMRGPU_STATUS_SUCCESS;
+}
 
-    // flop model of the reference: tfqmrgpu_linalg.hxx:587,625,684,703 and tfqmrgpu_blocksparse.hxx:198
-    double const blk = double(p.LM) * p.LN, nX = p.nnzbX;
-    double const fMult = double(p.nPairs()) * 8. * p.LM * blk, fDot = nX * 8. * blk, fNrm = nX * 4. * blk, fAxp = nX * 8. * blk;
-    p.flops_performed = fNrm + last.iteration * (2 * fMult + 2 * fDot + 2 * fNrm + 10 * fAxp) + last.nprobes * (fMult + fNrm);
-    if (userOp) p.flops_performed += userFlops - (2. * last.iteration + last.nprobes) * fMult;  // the operator's own count
+// flop model of the reference: tfqmrgpu_linalg.hxx:587,625,684,703 and tfqmrgpu_blocksparse.hxx:198
+struct FlopModel {
+    double fMult, fDot, fNrm, fAxp;
+    explicit FlopModel(Plan const& p) {
+        double const blk = double(p.LM) * p.LN, nX = p.nnzbX;
+        fMult = double(p.nPairs()) * 8. * p.LM * blk; fDot = nX * 8. * blk; fNrm = nX * 4. * blk; fAxp = nX * 8. * blk;
+    }
+    double solve(Ctl const& c) const { return fNrm + c.iteration * (2 * fMult + 2 * fDot + 2 * fNrm + 10 * fAxp) + c.nprobes * (fMult + fNrm); }
+};
+
+// Mixed precision 'm' (reference: dormant, tfqmrgpu.cu:42 "load float, multiply-accumulate double, store float"; documented as
+// "start with float and converge double", tfqmrgpu.h:72).  Iterative refinement: x, B, A in double; per cycle r = b - A x in double,
+// A d = r solved by the complex<float> tfQMR (its kernels unchanged; the right-hand side is the X-shaped R), x += d in double.  The
+// float iteration moves half the bytes of the double one; a cycle gains the digits a float solve delivers, the refinement's own
+// stopping test is max_rhs |b - A x| / |b| <= threshold in double.  maxIterations bounds the SUM of the inner iterations.
+static tfqmrgpuStatus_t run_mixed(Handle& h, Plan& p, double tol, int maxIt) {
+    hipStream_t const s = (hipStream_t)h.stream;
+    SolveOutcome o;
+    if (!p.buffer)  return run_tfqmr(h, p, DevPlan{}, tol, maxIt, TFQ_ERR(TFQMRGPU_POINTER_INVALID), 1., o);   // (the refusal travels through the ranks' vote)
+    if (p.opFn)     return run_tfqmr(h, p, DevPlan{}, tol, maxIt, TFQ_ERR(TFQMRGPU_NO_IMPLEMENTATION), 1., o);  // user-defined operators: 'z' and 'c' only
+    DevPlan const d = resolve(p), dz = resolveZ(p);
+    FlopModel const fm(p);
+    RefineArgs a{};
+    a.d = d; a.xz = (double*)dz.x; a.Bz = (double const*)dz.B; a.Yz = (double const*)d.v4;   // A x lives in v4 ... v7, free between two inner solves
+    a.bn2z = (double*)(p.buffer + p.wBn2z.offset); a.refine = (double*)(p.buffer + p.wRefine.offset); a.ilvZ = p.ilvZ;
+    if (maxIt <= 0) TFQ_HIP(hipMemsetAsync(a.xz, 0, p.wXz.bytes, s), TFQMRGPU_STATUS_LAUNCH_FAILED)   // no iteration at all: x = 0 is the answer
+    // what a float solve is asked for per cycle: a quarter of what is missing, but not more digits than float iterations deliver; a solve
+    // that reaches its floor earlier ends itself (Ctl::stallStop) and the next cycle continues from the double residual
+    double const kInnerFloor = 3e-5;
+    int used = 0, strikes = 0;
+    double res2 = 1e300, prev2 = 1e300;
+    tfqmrgpuStatus_t result = TFQMRGPU_STATUS_MAX_ITERATIONS;
+    for (int cycle = 0; ; ++cycle) {
+        if (cycle > 0) { spmm_apply(dz, dz.x, (void*)a.Yz, s); p.flops_performed += fm.fMult; }
+        a.cycle = cycle; a.innerTol = 1e-4; a.innerMaxIt = std::max(0, maxIt - used);
+        launch_refine_residual(a, s);
+        p.flops_performed += fm.fNrm;
+        if (auto const st = reduce_over_ranks(h, a.refine, 3, s)) return st;
+        double v[3];
+        TFQ_HIP(hipMemcpyAsync(v, a.refine, sizeof v, hipMemcpyDeviceToHost, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        if (v[2] > 0.) return TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);      // a rank failed
+        res2 = v[0];
+        p.cycleResidual.push_back(std::sqrt(res2));
+        p.refinementCycles = cycle;
+        if (v[1] > 0.) { result = TFQMRGPU_STATUS_BREAKDOWN; break; }      // the residual is not finite
+        if (res2 <= tol * tol) { result = TFQMRGPU_STATUS_SUCCESS; break; }
+        if (used >= maxIt) break;
+        if (cycle > 0) { strikes = (res2 > 0.25 * prev2) ? strikes + 1 : 0; if (strikes >= 2) break; }   // two cycles in a row gained less than a factor 2
+        prev2 = res2;
+        double const innerTol = std::min(0.5, std::max(kInnerFloor, 0.25 * tol / std::sqrt(res2)));
+        double const t2[2] = { innerTol * innerTol, innerTol * innerTol * 1e4 };   // Ctl::tol2, Ctl::target_bound2 (every rank the same values)
+        TFQ_HIP(hipMemcpyAsync(&d.ctl->tol2, t2, sizeof t2, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        if (auto const st = run_tfqmr(h, p, d, innerTol, maxIt - used, TFQMRGPU_STATUS_SUCCESS, res2, o)) return st;
+        used += o.last.iteration;
+        p.flops_performed += fm.solve(o.last) - fm.fNrm;                    // (|r|^2 of the set-up is the refinement's, counted above)
+        launch_refine_update(a, s);
+        p.flops_performed += 2. * p.nnzbX * p.LM * p.LN;
+    }
+    TFQ_HIP(hipGetLastError(), TFQMRGPU_STATUS_LAUNCH_FAILED)
+    p.flops_performed_all += p.flops_performed;
+    p.residuum_reached = std::sqrt(std::max(res2, 1.4e-76 * 1.4e-76));
+    p.iterations_needed = (TFQMRGPU_STATUS_SUCCESS == result) ? used : maxIt;
+    return result;
+}
+
+static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
+    for (int k = 0; k < TFQMRGPU_PROFILE_CLASSES; ++k) { p.profLaunches[k] = 0; p.profMs[k] = 0; p.profGatedLaunches[k] = 0; p.profGatedMs[k] = 0; p.profFirstLaunches[k] = 0; p.profFirstMs[k] = 0; }
+    p.boundHistory.clear(); p.cycleResidual.clear(); p.refinementCycles = 0;
+    p.iterations_needed = maxIt; p.flops_performed = 0;
+    if ('m' == p.precision) return run_mixed(h, p, tol, maxIt);
+    // what this rank can tell before it touches the device
+    tfqmrgpuStatus_t early = TFQMRGPU_STATUS_SUCCESS;
+    if (!p.buffer) early = TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    else if ('z' != p.precision && 'c' != p.precision) early = err(TFQMRGPU_PRECISION_MISSMATCH, __LINE__ % 10000, p.precision);
+    SolveOutcome o;
+    if (auto const st = run_tfqmr(h, p, early ? DevPlan{} : resolve(p), tol, maxIt, early, 1., o)) return st;
+    Ctl const& last = o.last;
+    FlopModel const fm(p);
+    p.flops_performed = fm.solve(last);
+    if (p.opFn) p.flops_performed += o.userFlops - (2. * last.iteration + last.nprobes) * fm.fMult;  // the operator's own count
     p.flops_performed_all += p.flops_performed;
     p.residuum_reached = std::sqrt(last.residual2_reached);
     p.iterations_needed = (1 == last.state) ? last.iterations_needed : maxIt;
@@ -540,9 +639,10 @@ tfqmrgpuStatus_t tfqmrgpu_bsrsv_bufferSize(tfqmrgpuHandle_t handle, tfqmrgpuBsrs
     }
     if (nullptr == pBufferSizeInBytes) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
     if (!blockSizeAllowed(LM, LN)) return err(TFQMRGPU_BLOCKSIZE_MISSING, LN, LM); // tfqmrgpu.cu:70
-    // 'm' is accepted here and refused by solve, as in the reference (tfqmrgpu.cu:42-44); size it like 'c'
+    // 'm': accepted here AND solved (the reference accepts it here and refuses it in solve, tfqmrgpu.cu:42-44, 386): float vectors for
+    // the iteration plus x, B and A in double (tfq_plan.cpp: layoutBuffer)
     tfqmrgpuStatus_t st;
-    try { st = layoutBuffer(*p, LM, LN, ('m' == prec) ? 'c' : prec); }
+    try { st = layoutBuffer(*p, LM, LN, prec); }
     catch (std::bad_alloc const&) { return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED); }
     if (p->opScratch) { (void)hipFree(p->opScratch); p->opScratch = nullptr; }   // sized for the previous block shape
     p->precision = prec;
@@ -588,7 +688,7 @@ tfqmrgpuStatus_t tfqmrgpu_bsrsv_setBuffer(tfqmrgpuHandle_t handle, tfqmrgpuBsrsv
         GlibcRand rng(1);
         float const denom = 1. / 2147483647;                            // tfqmrgpu_linalg.hxx:799-801
         for (size_t i = 0; i < n; ++i) v3[i] = rng.next() * denom;
-        st = transfer_blocks(*p, s, 0, false, d.v3, v3.data(), d.u2i, p->nnzbX, p->LM, p->LN, TFQMRGPU_LAYOUT_RRRRIIII, false, false);
+        st = transfer_blocks(*p, s, 0, false, Target{d.v3, false, p->ilv}, v3.data(), d.u2i, p->nnzbX, p->LM, p->LN, TFQMRGPU_LAYOUT_RRRRIIII, false, false);
         if (st) return st;
         p->v3IsHash = false;
     } else {
@@ -636,14 +736,20 @@ static tfqmrgpuStatus_t set_or_get(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t 
     }
     if (nnzb < 1) return TFQMRGPU_STATUS_SUCCESS;
     if (nullptr == p->buffer) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    bool const mixed = ('m' == p->precision);
     bool const is_double = ('z' == p->precision);
-    if (('z' == lower(precision)) != is_double) return err(TFQMRGPU_PRECISION_MISSMATCH, __LINE__ % 10000, precision);
+    bool const user_double = ('z' == lower(precision));
+    // 'z' plans take double data, every other plan float data (tfqmrgpu.cu:538-542); a mixed-precision plan takes either: its copies of
+    // A, B and X are double (A also float), the values are converted on the way
+    if (!mixed && user_double != is_double) return err(TFQMRGPU_PRECISION_MISSMATCH, __LINE__ % 10000, precision);
     if (nullptr == values) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
     hipStream_t const s = (hipStream_t)h->stream;
-    DevPlan const d = resolve(*p);
-    void* native = (0 == which) ? d.A : (1 == which) ? d.B : d.x;
+    DevPlan const d = mixed ? resolveZ(*p) : resolve(*p);
+    Target const to{ (0 == which) ? d.A : (1 == which) ? d.B : d.x, d.dbl, d.ilv };
+    Target const floatA{ p->buffer + p->wA.offset, false, p->ilv };              // mixed: the inner solves multiply with A in float
     uint32_t const* u2n = (2 == which) ? d.u2i : nullptr;
-    auto const st = transfer_blocks(*p, s, is_get ? 1 : 0, is_double, native, values, u2n, nnzb, nR, nC, layout, trans, conj);
+    auto const st = transfer_blocks(*p, s, is_get ? 1 : 0, user_double, to, values, u2n, nnzb, nR, nC, layout, trans, conj, nullptr,
+                                    (mixed && 0 == which && !is_get) ? &floatA : nullptr);
     if (!st && 1 == which) p->haveB = true;
     return st;
 }
@@ -802,6 +908,21 @@ tfqmrgpuStatus_t tfqmrgpuExt_getProfileFirst(tfqmrgpuBsrsvPlan_t plan, int64_t* 
     return TFQMRGPU_STATUS_SUCCESS;
 }
 
+tfqmrgpuStatus_t tfqmrgpuExt_setThreeProductMultiply(tfqmrgpuBsrsvPlan_t plan, int on) {
+    auto p = asPlan(plan);
+    if (!p) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    p->threeProducts = (0 != on);
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+int32_t tfqmrgpuExt_getRefinementHistory(tfqmrgpuBsrsvPlan_t plan, double* residual, int32_t capacity) {
+    auto p = asPlan(plan);
+    if (!p) return -1;
+    auto const n = int32_t(p->cycleResidual.size());
+    for (int32_t i = 0; i < std::min(n, capacity); ++i) if (residual) residual[i] = p->cycleResidual[i];
+    return n;
+}
+
 tfqmrgpuStatus_t tfqmrgpuExt_setShadowMode(tfqmrgpuBsrsvPlan_t plan, int mode) {
     auto p = asPlan(plan);
     if (!p) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
@@ -815,7 +936,7 @@ tfqmrgpuStatus_t tfqmrgpuExt_setShadowVector(tfqmrgpuHandle_t handle, tfqmrgpuBs
     if (!p || !h || !v3 || !p->buffer) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
     DevPlan const d = resolve(*p);
     p->v3IsHash = false;
-    return transfer_blocks(*p, (hipStream_t)h->stream, 0, false, d.v3, (void*)v3, d.u2i, p->nnzbX, p->LM, p->LN,
+    return transfer_blocks(*p, (hipStream_t)h->stream, 0, false, Target{d.v3, false, p->ilv}, (void*)v3, d.u2i, p->nnzbX, p->LM, p->LN,
                            TFQMRGPU_LAYOUT_RRRRIIII, false, false);
 }
 
@@ -823,7 +944,7 @@ tfqmrgpuStatus_t tfqmrgpuExt_getShadowVector(tfqmrgpuHandle_t handle, tfqmrgpuBs
     auto p = asPlan(plan); auto h = (Handle*)handle;
     if (!p || !h || !v3 || !p->buffer) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
     DevPlan const d = resolve(*p);
-    return transfer_blocks(*p, (hipStream_t)h->stream, 1, false, d.v3, (void*)v3, d.u2i, p->nnzbX, p->LM, p->LN,
+    return transfer_blocks(*p, (hipStream_t)h->stream, 1, false, Target{d.v3, false, p->ilv}, (void*)v3, d.u2i, p->nnzbX, p->LM, p->LN,
                            TFQMRGPU_LAYOUT_RRRRIIII, false, false);
 }
 
@@ -842,7 +963,7 @@ tfqmrgpuStatus_t tfqmrgpuExt_getWorkVector(tfqmrgpuHandle_t handle, tfqmrgpuBsrs
     Stage st{nullptr, std::min<size_t>(p->S, size_t(64) << 20)};
     st.bytes = std::max(st.bytes, size_t(2) * p->LM * p->LN * ('z' == p->precision ? 8 : 4));
     if (hipSuccess != hipMalloc((void**)&st.ptr, st.bytes)) return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED);
-    auto const status = transfer_blocks(*p, (hipStream_t)h->stream, 1, 'z' == p->precision, v, values, d.u2i, p->nnzbX, p->LM, p->LN,
+    auto const status = transfer_blocks(*p, (hipStream_t)h->stream, 1, 'z' == p->precision, Target{v, 'z' == p->precision, p->ilv}, values, d.u2i, p->nnzbX, p->LM, p->LN,
                                         TFQMRGPU_LAYOUT_RRRRIIII, false, false, &st);
     (void)hipFree(st.ptr);
     return status;
@@ -859,12 +980,14 @@ tfqmrgpuStatus_t tfqmrgpuExt_multiply(tfqmrgpuHandle_t handle, char precision, i
 tfqmrgpuStatus_t tfqmrgpuExt_applyOperator(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, int repetitions) {
     auto p = asPlan(plan); auto h = (Handle*)handle;
     if (!p || !h || !p->buffer) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
-    if ('z' != p->precision && 'c' != p->precision) return err(TFQMRGPU_PRECISION_MISSMATCH, __LINE__ % 10000, p->precision);
     if (p->opFn) return TFQ_ERR(TFQMRGPU_NO_IMPLEMENTATION);       // a user-defined operator is the caller's to apply
     hipStream_t const s = (hipStream_t)h->stream;
-    DevPlan const d = resolve(*p);
-    for (int r = 0; r < std::max(1, repetitions); ++r) spmm_apply(d, d.x, d.v9, s);   // the work vector v9 is free outside of a solve
-    TFQ_HIP(hipMemcpyAsync(d.x, d.v9, p->S, hipMemcpyDeviceToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+    bool const mixed = ('m' == p->precision);
+    DevPlan const d = mixed ? resolveZ(*p) : resolve(*p);           // mixed: the double side (x, A), the product in v4 ... v7
+    void* const y = mixed ? d.v4 : d.v9;                            // the work vectors are free outside of a solve
+    for (int r = 0; r < std::max(1, std::abs(repetitions)); ++r) spmm_apply(d, d.x, y, s);
+    // repetitions < 0: |repetitions| launches and nothing else (timing: X stays as it is, the product is left in the work vector)
+    if (repetitions >= 0) TFQ_HIP(hipMemcpyAsync(d.x, y, mixed ? p->wXz.bytes : p->S, hipMemcpyDeviceToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
     TFQ_HIP(hipGetLastError(), TFQMRGPU_STATUS_LAUNCH_FAILED)
     return TFQMRGPU_STATUS_SUCCESS;
 }
@@ -883,6 +1006,7 @@ tfqmrgpuStatus_t tfqmrgpuExt_commInit(tfqmrgpuHandle_t handle, int nranks, int r
     void* comm = nullptr;
     if (g_rccl.CommInitRank(&comm, nranks, u, rank)) return TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
     h->comm = comm; h->nranks = nranks; h->rank = rank;
+    if (!h->voteBuf) TFQ_HIP(hipMalloc((void**)&h->voteBuf, 4 * sizeof(double)), TFQMRGPU_STATUS_ALLOCATION_FAILED)   // for the vote in front of every solve
     return TFQMRGPU_STATUS_SUCCESS;
 }
 
@@ -905,6 +1029,7 @@ tfqmrgpuStatus_t tfqmrgpuExt_setReduceCallback(tfqmrgpuHandle_t handle, tfqmrgpu
     auto h = (Handle*)handle;
     if (!h) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
     h->reduceFn = fn; h->reduceCtx = ctx;
+    if (fn && !h->voteBuf) TFQ_HIP(hipMalloc((void**)&h->voteBuf, 4 * sizeof(double)), TFQMRGPU_STATUS_ALLOCATION_FAILED)
     return TFQMRGPU_STATUS_SUCCESS;
 }
 

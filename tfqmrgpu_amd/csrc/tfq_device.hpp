@@ -26,7 +26,8 @@ struct Ctl {
     int32_t iterations_needed;
     int32_t nprobes;
     int32_t xpend;             // x += eta2*v7 of the last iteration has not been applied yet
-    int32_t pad[1];
+    int32_t stallStop;         // inner solves of the mixed-precision mode: a probe that finds the true residual no better than 0.7 x the
+                               // previous probe's ends the solve (state 3): the float iteration has reached its floor
 };
 static_assert(sizeof(Ctl) == 112, "Ctl is copied as a whole");
 
@@ -54,9 +55,26 @@ struct DevPlan {
     uint32_t const *chunkFirst, *chunkCol, *colChunkPtr, *colStart, *bOfX, *order;
     uint32_t const *starts, *pairs, *subset, *bColPtr, *bList, *u2i, *rowI;
     int32_t const* origCol;
+    void const* R;                             // not null: the right-hand side of THIS solve is the X-shaped vector R (the residual of the
+                                               // mixed-precision refinement) instead of B scattered onto zeros; its |r|^2 per right-hand side
+                                               // has been set up by k_refine_init_col
+    int m3;                                    // three real products per complex one in the double multiplies above 16 x 16 (opt-in)
 };
 
 DevPlan resolve(Plan const& p);
+
+// mixed precision 'm': the double-precision side of the plan (x, B, A, the product A x) next to the float plan `d` of the inner solves
+struct RefineArgs {
+    DevPlan d;                                 // the inner (float) plan: chunk tables, scalars, R = d.R
+    double* xz; double const* Bz; double const* Yz;   // solution, right-hand sides, A x (all double, element order ilvZ)
+    double* bn2z;                              // [nCols][LN] |b|^2, kept from cycle 0
+    double* refine;                            // {max_rhs |r|^2 / |b|^2, a value was not finite, a rank failed}
+    int ilvZ;
+    int cycle;                                 // 0: x = 0, r = b (Yz is not read)
+    double innerTol; int innerMaxIt;
+};
+void launch_refine_residual(RefineArgs const& r, hipStream_t s);   // r = b - A x -> R (float), |r|^2 records, inner solve set up, refine[]
+void launch_refine_update(RefineArgs const& r, hipStream_t s);     // x (double) += x (float) of the inner solve
 
 // ---- shadow vector -------------------------------------------------------------------------------
 // The reference fills v3 with cuRAND XORWOW uniforms on the GPU and rand()/RAND_MAX on the CPU
@@ -112,7 +130,8 @@ tfqmrgpuStatus_t launch_multiply(char precision, int lm, int ln, uint32_t nnzbY,
 // direction 0: user -> native (setMatrix), 1: native -> user (getMatrix); one batch of user blocks
 // [firstUser, firstUser + nBlocks) whose raw bytes sit in `stage`; u2n: user -> native block index
 // ilv: element order of the library-side blocks (see ilv_offset)
-void launch_convert(int direction, bool dbl, void* native, void* stage, uint32_t const* u2n,
+// userDbl / nativeDbl: precision of the caller's array and of the library-side array (they differ in the mixed-precision mode only)
+void launch_convert(int direction, bool userDbl, bool nativeDbl, void* native, void* stage, uint32_t const* u2n,
     uint32_t firstUser, uint32_t nBlocks, int nR, int nC, int layout, bool trans, bool conj, int ilv, hipStream_t s);
 void launch_shadow_hash(DevPlan const& d, hipStream_t s);
 

@@ -28,31 +28,37 @@ __device__ inline uint32_t user_offset(int layout, bool trans, int nR, int nC, i
 // One work group per USER block ub = firstUser + blockIdx.x; `stage` holds the raw user blocks of the
 // current batch (block 0 of the stage is user block firstUser); u2n maps user -> native block index
 // (nullptr: identity, used for A and B; X-shaped operators pass the column-sorted permutation).
-template <typename R>
-__global__ __launch_bounds__(256) void k_convert(int direction, R* native, R* stage, uint32_t const* u2n,
+template <typename R, typename U>   // R: library side, U: caller's side
+__global__ __launch_bounds__(256) void k_convert(int direction, R* native, U* stage, uint32_t const* u2n,
     uint32_t firstUser, int nR, int nC, int layout, bool trans, bool conj, int ilv)
 {
     uint32_t const ub = firstUser + blockIdx.x;
     uint32_t const nb = u2n ? u2n[ub] : ub;
     int const E = 2 * nR * nC;
-    R* ublock = stage + size_t(blockIdx.x) * E;
+    U* ublock = stage + size_t(blockIdx.x) * E;
     R* nblock = native + size_t(nb) * E;
     for (int e = threadIdx.x; e < E; e += 256) {
         int const c = e / (nR * nC), r = (e % (nR * nC)) / nC, s = e % nC;
         uint32_t const uo = user_offset(layout, trans, nR, nC, r, s, c);
-        R const sign = (conj && c) ? R(-1) : R(1);
+        bool const neg = (conj && c);
         int const ne = c * nR * nC + plane_offset(ilv, r, s, nC);   // where the library keeps element (c, r, s)
-        if (0 == direction) nblock[ne] = sign * ublock[uo];
-        else                ublock[uo] = sign * nblock[ne];
+        if (0 == direction) { R const v = R(ublock[uo]); nblock[ne] = neg ? -v : v; }
+        else                { U const v = U(nblock[ne]); ublock[uo] = neg ? -v : v; }
     }
 }
 
-void launch_convert(int direction, bool dbl, void* native, void* stage, uint32_t const* u2n,
+void launch_convert(int direction, bool userDbl, bool nativeDbl, void* native, void* stage, uint32_t const* u2n,
     uint32_t firstUser, uint32_t nBlocks, int nR, int nC, int layout, bool trans, bool conj, int ilv, hipStream_t s)
 {
     if (0 == nBlocks) return;
-    if (dbl) k_convert<double><<<dim3(nBlocks), dim3(256), 0, s>>>(direction, (double*)native, (double*)stage, u2n, firstUser, nR, nC, layout, trans, conj, ilv);
-    else     k_convert<float ><<<dim3(nBlocks), dim3(256), 0, s>>>(direction, (float*)native, (float*)stage, u2n, firstUser, nR, nC, layout, trans, conj, ilv);
+    dim3 const g(nBlocks), b(256);
+    if (nativeDbl) {
+        if (userDbl) k_convert<double, double><<<g, b, 0, s>>>(direction, (double*)native, (double*)stage, u2n, firstUser, nR, nC, layout, trans, conj, ilv);
+        else         k_convert<double, float ><<<g, b, 0, s>>>(direction, (double*)native, (float*)stage, u2n, firstUser, nR, nC, layout, trans, conj, ilv);
+    } else {
+        if (userDbl) k_convert<float, double><<<g, b, 0, s>>>(direction, (float*)native, (double*)stage, u2n, firstUser, nR, nC, layout, trans, conj, ilv);
+        else         k_convert<float, float ><<<g, b, 0, s>>>(direction, (float*)native, (float*)stage, u2n, firstUser, nR, nC, layout, trans, conj, ilv);
+    }
 }
 
 // ---- shadow vector: the counter-based hash of tfq_device.hpp written out (k_dot35 and the GLIBC/user modes read v3) ----

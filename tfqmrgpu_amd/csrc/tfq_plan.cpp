@@ -8,6 +8,7 @@
 // The search itself is done with one sorted (column, position) list per block row, so the
 // cost is O(nPairs log) instead of the reference's O(nnzbX * nnz/rowA * nnz/rowX).
 #include "tfq_plan.hpp"
+#include "tfq_switch.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -231,18 +232,26 @@ tfqmrgpuStatus_t analyse(Plan& p, int mb,
 // layout here is this library's own: no 2^ceil(log2 nnzbX) reduction scratch (zvv/dvv), instead
 // one small partial-sum record per chunk.
 tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
+    // 'm' (mixed precision): the iteration runs on a complex<float> plan; x, B, A are kept in double next to it (below)
+    bool const mixed = ('m' == precision);
+    char const iterPrec = mixed ? 'c' : precision;
     p.LM = LM; p.LN = LN; p.precision = precision;
-    p.realBytes = ('z' == precision) ? 8 : 4;
+    p.realBytes = ('z' == iterPrec) ? 8 : 4;
     size_t const blockElems = size_t(2) * LM * LN;
     p.S = size_t(p.nnzbX) * blockElems * p.realBytes;
     // groups of rows interleaved (16-byte accesses for one column) where a multiply kernel is written for it: 16 x 16 and 8 x 8
-    // complex<double> (pairs), 16 x 16, 16 x 32 and 32 x 32 complex<float> (quads).  TFQMRGPU_ILV=0 keeps the native order everywhere
-    // (A/B runs), =16: only 16 x 16 z, =2: only the double shapes, =3: all but the float shapes beyond 16 x 16
-    static int const ilvEnv = [] { auto v = std::getenv("TFQMRGPU_ILV"); return v ? std::atoi(v) : 1; }();
-    p.ilv = 0;
-    if (ilvEnv && 'z' == precision && ((16 == LM && 16 == LN) || (8 == LM && 8 == LN && ilvEnv != 16))) p.ilv = 2;
-    if ((1 == ilvEnv || 3 == ilvEnv) && 'c' == precision && 16 == LM && 16 == LN) p.ilv = 4;
-    if (1 == ilvEnv && 'c' == precision && (16 == LM || 32 == LM) && 32 == LN) p.ilv = 4;   // 16 x 32, 32 x 32 (k_spmm_ilvf)
+    // complex<double> (pairs), 16 x 16, 16 x 32 and 32 x 32 complex<float> (quads).  A lab build (-DTFQ_LAB) can keep the native order
+    // with TFQMRGPU_ILV=0 (A/B runs), =16: only 16 x 16 z, =2: only the double shapes, =3: all but the float shapes beyond 16 x 16
+    int const ilvEnv = lab_switch("TFQMRGPU_ILV", 1);
+    auto const ilvOf = [&](char prec) {
+        int ilv = 0;
+        if (ilvEnv && 'z' == prec && ((16 == LM && 16 == LN) || (8 == LM && 8 == LN && ilvEnv != 16))) ilv = 2;
+        if ((1 == ilvEnv || 3 == ilvEnv) && 'c' == prec && 16 == LM && 16 == LN) ilv = 4;
+        if (1 == ilvEnv && 'c' == prec && (16 == LM || 32 == LM) && 32 == LN) ilv = 4;   // 16 x 32, 32 x 32 (k_spmm_ilvf)
+        return ilv;
+    };
+    p.ilv = ilvOf(iterPrec);
+    p.ilvZ = mixed ? ilvOf('z') : 0;
 
     // chunks: runs of CH blocks inside one column, sized so that a chunk of one vector is 8..16 KiB and the
     // grid has a few thousand work groups when the problem is large enough
@@ -250,7 +259,7 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
         size_t const blockBytes = blockElems * p.realBytes;
         size_t target = p.S / 4096;
         size_t maxKiB = 16;   // P2: 64 -> 16 KiB takes the vector kernels from 4.2 to 17 rounds of work groups (tail 16 % -> 1 %): iteration 2.80 -> 2.69 ms
-        if (auto v = std::getenv("TFQMRGPU_CHUNK_KIB")) maxKiB = std::max(8, std::atoi(v));
+        maxKiB = size_t(std::max(8, lab_switch("TFQMRGPU_CHUNK_KIB", 16)));
         target = std::min<size_t>(std::max<size_t>(target, 8 * 1024), maxKiB * 1024);
         uint32_t CH = uint32_t(std::max<size_t>(1, target / blockBytes));
         // every wave of a work group wants a unit of work: the MFMA multiply cuts a block into strips of 16 or
@@ -281,7 +290,7 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
         // (Tried and dropped in round 1: one chunk per WAVE with the 4 waves of a work group on 4 columns
         //  of the same band -- 20 % slower; with all A traffic removed artificially the kernel only
         //  reaches 0.77 ms, so A re-reads are not what bounds it any more.)
-        auto envu = [](char const* name, uint32_t dflt) { auto v = std::getenv(name); return v ? uint32_t(std::atoi(v)) : dflt; };
+        auto envu = [](char const* name, uint32_t dflt) { return uint32_t(lab_switch(name, int(dflt))); };
         uint32_t const n = uint32_t(c.col.size());
         uint32_t const mode = envu("TFQMRGPU_ORDER", 1), G = std::max(1u, envu("TFQMRGPU_ORDER_G", 4));   // 8 until the epilogue streams went non-temporal / the shadow vector stopped being read: now 4 (P2 iteration 2.649 -> 2.626 ms, 8x8 z 2.819 -> 2.792, 2: 2.655)
         uint32_t const BM = std::max(1u, envu("TFQMRGPU_ORDER_BANDMULT", 1));   // bands of BM*CH block rows
@@ -312,7 +321,7 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     take(p.wV4, p.S); take(p.wV5, p.S); take(p.wV6, p.S);
     take(p.wV7, p.S); take(p.wV8, p.S); take(p.wV9, p.S);
     take(p.wV3, size_t(p.nnzbX) * blockElems * sizeof(float)); // the shadow vector is float for 'z' too
-    take(p.wB, size_t(p.nnzbB) * blockElems * p.realBytes);
+    take(p.wB, mixed ? 0 : size_t(p.nnzbB) * blockElems * p.realBytes);   // ('m' keeps B in double only, wBz)
     size_t const cs = size_t(p.nCols) * 2 * LN * p.realBytes;
     take(p.wRho, cs); take(p.wAlfa, cs); take(p.wBeta, cs); take(p.wC67, cs); take(p.wEta, cs);
     take(p.wC67a, cs); take(p.wEta2, cs);
@@ -341,6 +350,18 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     take(p.wU2I, size_t(p.nnzbX) * sizeof(uint32_t));
     take(p.wRowI, size_t(p.nnzbX) * sizeof(uint32_t));
     take(p.wA, size_t(p.nnzbA) * 2 * LM * LM * p.realBytes);
+    if (mixed) {
+        // Mixed precision: float vectors for the iteration (above), and in double the solution, B, A (the refinement's residual
+        // b - A x is computed in double) and |b|^2.  The product A x of the refinement lives in the work vectors v4 ... v7, which are
+        // free between two inner solves (4 float vectors = 2 double ones).  All in all 11 float-sized vectors (x, v4 ... v9, v3, R, and
+        // x in double) against 15 for a 'z' plan.
+        take(p.wXz, size_t(p.nnzbX) * blockElems * sizeof(double));
+        take(p.wR, p.S);
+        take(p.wBz, size_t(p.nnzbB) * blockElems * sizeof(double));
+        take(p.wAz, size_t(p.nnzbA) * 2 * LM * LM * sizeof(double));
+        take(p.wBn2z, size_t(p.nCols) * LN * sizeof(double));
+        take(p.wRefine, 256);
+    }
     p.bufferBytes = at + 256;
     return TFQMRGPU_STATUS_SUCCESS;
 }

@@ -67,12 +67,13 @@ struct Plan {
 
     // ---- fixed by bufferSize -----------------------------------------------------------------
     int LM = 0, LN = 0;
-    char precision = 0;                // 'c' or 'z' (or 'm', accepted but not solvable)
-    size_t realBytes = 0;              // 4 or 8
+    char precision = 0;                // 'c', 'z' or 'm' (mixed: float inner iterations, double refinement; tfq_api.hip: run_mixed)
+    size_t realBytes = 0;              // 4 or 8 (the storage precision of the iteration vectors: 4 for 'm')
     size_t S = 0;                      // bytes of one X-shaped vector
     size_t bufferBytes = 0;
     bool aOnce = false;                // nPairs <= 1.5 x the A blocks that occur in the pair list: A is streamed once per multiply
     int ilv = 0;                       // element order inside the blocks of this plan's buffer (tfq_device.hpp: ilv_offset)
+    int ilvZ = 0;                      // 'm': element order of the double-precision arrays (x, B, A, A x), the one a 'z' plan of this shape has
 
     // windows into the user's device buffer
     Window wX, wV4, wV5, wV6, wV7, wV8, wV9, wV3, wB, wA;
@@ -84,6 +85,9 @@ struct Plan {
     Window wColRec;                            // per-column stopping-test record [nCols][2] double
     Window wChunkFirst, wChunkCol, wColChunkPtr, wColStart, wOrigCol, wBofX, wOrder;
     Window wStarts, wPairs, wSubset, wBColPtr, wBList, wU2I, wRowI;
+    // 'm' only: the solution, B and A in double; the residual of the refinement as the right-hand side of the inner (float) solve,
+    // |b|^2 per right-hand side, the record of the refinement's stopping test
+    Window wXz, wBz, wAz, wR, wBn2z, wRefine;
 
     char* buffer = nullptr;            // device buffer registered by setBuffer
     static constexpr int kDepth = 4;   // iterations the host keeps enqueued ahead of the stopping decision
@@ -92,6 +96,9 @@ struct Plan {
     int shadowMode = TFQMRGPU_SHADOW_HASH;
     bool v3IsHash = false;             // the buffer's v3 holds the counter-based hash (set by setBuffer, cleared by a user-supplied vector)
     bool haveB = false;
+    bool threeProducts = false;        // tfqmrgpuExt_setThreeProductMultiply: Gauss' three real products per complex one in the double multiplies
+    std::vector<double> cycleResidual; // 'm': relative residual (double arithmetic) in front of every inner solve and at the end
+    int refinementCycles = 0;
     // user-defined operator (tfqmrgpu_ext.h section 5): callback, and library-owned device scratch
     // [xu | yu | i2u | colindx in the caller's block order]
     void* opFn = nullptr; void* opCtx = nullptr;

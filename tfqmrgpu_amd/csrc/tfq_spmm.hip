@@ -33,6 +33,7 @@
 
 #include "tfq_device.hpp"
 #include "tfq_vec.hpp"
+#include "tfq_switch.hpp"
 
 namespace tfq {
 
@@ -46,7 +47,8 @@ struct SpmmArgs {
     uint32_t CH;
     Ctl const* ctl; int gate;          // 0: always run, 1: skip when the solve has stopped, 2: only when probing
     void* e0; void const* e1; void const* sc; float const* v3;
-    void const* B; uint32_t const* bOfX;
+    void const* B; uint32_t const* bOfX;       // bOfX == nullptr: B is a whole X-shaped vector (block y of B belongs to Y block y: the
+                                               // residual of the mixed-precision refinement as the right-hand side, DevPlan::R)
     double* pz; double* pd;
     void const* Yext; uint32_t const* yPerm;   // k_spmm_direct only: take block y of the product from Yext[yPerm[y]]
     int hashV3;                        // the shadow vector is the counter-based hash (tfq_device.hpp): recompute it, do not read it
@@ -54,6 +56,7 @@ struct SpmmArgs {
     int ilv;                           // element order of the plan's blocks (tfq_device.hpp: ilv_offset); the plain mode is always native
     int aOnce;                         // every A block is used about once per multiply (few block columns): stream A past the caches
     int first;                         // EPI_XPAY_DOT in the first iteration of a solve: old v4 = v8 = 0 by definition, not read (DevPlan::first)
+    int m3;                            // double shapes above 16 x 16: three real products per complex one (tfqmrgpuExt_setThreeProductMultiply)
 };
 
 // data that a kernel touches once (epilogue vectors) moves non-temporally, so that the stream does not push the A and
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(256) void k_spmm_direct(SpmmArgs a) {
             }
         }
         uint32_t bq = 0xffffffffu;
-        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
+        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX ? a.bOfX[y] : y;
 #pragma unroll
         for (int n = 0; n < NACC; ++n) {
             int const e = e0 + n * 256;
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at leas
         for (int i = 0; i < NSET - 1; ++i) if (t + i < nT) mma(o[i]);
 
         uint32_t bq = 0xffffffffu;
-        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
+        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX ? a.bOfX[y] : y;
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
@@ -699,6 +702,9 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
             if (q0 < q1) fetch(o0, q0);
             if (q0 + 1 < q1) fetch(o1, q0 + 1);
         }
+        // (r03, profiles/r03_ab_exact_waits.txt: the conditional prefetches make the compiler wait with vmcnt(0) in front of every pair of
+        //  products; both forms with exact waits -- prefetch index clamped to the last product, or straight-line tails behind a loop that
+        //  always prefetches -- measured 4-8 % SLOWER on P2: redundant cache-hot fetches, or 192 VGPRs = two waves per SIMD)
         uint32_t q = q0;
         for (; q + 2 <= q1; q += 2) {
             mma(o0);
@@ -709,7 +715,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
         if (q < q1) mma(o0);
 
         uint32_t bq = 0xffffffffu;
-        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
+        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX ? a.bOfX[y] : y;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             // the shadow vector recomputed: one hash for this pair of rows (tfq_device.hpp: shadow_quad).  Drawn here, inside the loop:
@@ -862,7 +868,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
         f4v yr, yi, nr, ni;
         f4v br = f4v{0, 0, 0, 0}, bi = f4v{0, 0, 0, 0};
         if constexpr (EPI == EPI_RESIDUAL) {
-            uint32_t const bq = a.bOfX[y];
+            uint32_t const bq = a.bOfX ? a.bOfX[y] : y;
             if (bq != 0xffffffffu) { R const* b = (R const*)a.B + size_t(bq) * 2 * P + mine; br = *(f4v const*)b; bi = *(f4v const*)(b + P); }
         }
 #pragma unroll
@@ -1018,7 +1024,7 @@ __global__ __launch_bounds__(256, (LN <= 32 ? 3 : 2)) void k_spmm_ilvf(SpmmArgs 
         }
 
         uint32_t bq = 0xffffffffu;
-        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
+        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX ? a.bOfX[y] : y;
 #pragma unroll
         for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
@@ -1206,7 +1212,7 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8(SpmmArgs a) {
             __builtin_nontemporal_store(yM, (d2v*)((R*)a.Y + yoff));
             __builtin_nontemporal_store(cp ? ni : nr, (d2v*)((R*)a.e0 + yoff));
         } else if constexpr (EPI == EPI_RESIDUAL) {       // |A x - b|^2, nothing stored (tfqmrgpu_core.hxx:265-269)
-            uint32_t const bq = a.bOfX[y];
+            uint32_t const bq = a.bOfX ? a.bOfX[y] : y;
             d2v bM = d2v{0, 0};
             if (bq != 0xffffffffu) bM = *(d2v const*)((R const*)a.B + size_t(bq) * 2 * P + mine);
             d2v const bO = xor8(bM), br = cp ? bO : bM, bi = cp ? bM : bO;
@@ -1329,7 +1335,7 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
         }
 
         uint32_t bq = 0xffffffffu;
-        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
+        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX ? a.bOfX[y] : y;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             __builtin_amdgcn_wave_barrier();
@@ -1438,7 +1444,7 @@ __global__ __launch_bounds__(256) void k_spmm_small4(SpmmArgs a) {
         }
         if (valid) {
             uint32_t bq = 0xffffffffu;
-            if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX[y];
+            if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX ? a.bOfX[y] : y;
             int const eb = i * LN + j;
             epilogue<R, EPI, false>(a, size_t(y) * 2 * P + eb, P, yr, yi, sr, si, bq, eb, part);
         }
@@ -1529,26 +1535,28 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
         // (not for 32 x 32 float: the prefetched operands take the fused kernels from 168 / 132 to 224 / 198 VGPRs = two waves per SIMD
         //  instead of three; measured on config 3: 0.2998 / 0.2930 ms with, 0.2947 / 0.2887 ms without)
         constexpr bool pre = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) && ((LN / 16) * sizeof(R) <= 8) && !(sizeof(R) == 4 && LM == 32 && LN == 32);
-        static int const use_pre = [] { auto v = std::getenv("TFQMRGPU_EPI_PREFETCH"); return v ? std::atoi(v) : 1; }();
-        // three real products per complex one where the matrix pipe bounds the kernel and the precision has room:
-        // double, every shape but 16 x 16 (whose multiply is bound by the operand stream from beyond the L2: 0.486 ms on
-        // P2 with either form).  Not in float: Im = P3 - P1 - P2 carries the rounding of the real parts, and the float
-        // floor of the FD fixture (4.6e-5) moves above its threshold of 1e-4 (status 9 instead of 0).
-        static int const use_m3 = [] { auto v = std::getenv("TFQMRGPU_3M"); return v ? std::atoi(v) : 1; }();
+        static int const use_pre = lab_switch("TFQMRGPU_EPI_PREFETCH", 1);
+        // Three real products per complex one (Gauss) where the matrix pipe bounds the kernel: double, every shape but 16 x 16
+        // (whose multiply is bound by the operand stream: 0.486 ms on P2 with either form).  Im = P3 - P1 - P2 carries the rounding
+        // of the real parts: an imaginary part 10^-k times smaller than the real part loses k digits against the four-product form.
+        // A drop-in caller did not ask for that, so it is OPT-IN per plan (tfqmrgpuExt_setThreeProductMultiply; until r02 it was the
+        // default); never in float (the float floor of the FD fixture, 4.6e-5, moves above its threshold of 1e-4).
+        // Lab builds: TFQMRGPU_3M=1 everywhere above 16 x 16, 2: 16 x 16 too.
+        static int const use_m3 = lab_switch("TFQMRGPU_3M", 0);
         // the shadow vector recomputed in registers where it is the library's hash and a lane owns one column (16 x 16): the
         // fused kernels then read S/2 (`z`) or S (`c`) less (P2: 0.743 / 0.684 -> 0.719 / 0.673 ms); wider shapes and the
         // tile kernels lose and keep reading it (measured with the hash everywhere: 8 x 8 z +4 %, 32 x 32 c fused +19 %, 16 x 64 c
         // iteration +18 %, 32 x 64 c +41 %: more registers, and the hash competes with the epilogue for the vector ALU;
         // 16 x 32 z and 64 x 64 z would gain 1 %)
         constexpr bool canHash = (LN == 16) && (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
-        bool const m3 = sizeof(R) == 8 && ((use_m3 && (LM / 16) * (LN / 16) >= 2) || use_m3 >= 2);   // TFQMRGPU_3M=2: 16 x 16 too (A/B runs)
+        bool const m3 = sizeof(R) == 8 && (((use_m3 || a.m3) && (LM / 16) * (LN / 16) >= 2) || use_m3 >= 2);
         bool const p = pre && use_pre;
         // unconditional (clamped) operand prefetch where a strip has at least 8 slices per block product (LM >= 32)
         constexpr bool canClamp = (LM >= 32);
-        static int const use_clamp = [] { auto v = std::getenv("TFQMRGPU_CLAMP"); return v ? std::atoi(v) : 1; }();
-        // TFQMRGPU_DEEP=1: four operand sets for 32 x 32 float (measured on config 3: plain multiply 90.8 -> 94.8 TFLOP/s, but the
-        // fused kernel with its epilogue prefetch spills: 0.317 -> 0.350 ms) -- off by default
-        static int const use_deep = [] { auto v = std::getenv("TFQMRGPU_DEEP"); return v ? std::atoi(v) : 0; }();
+        static int const use_clamp = lab_switch("TFQMRGPU_CLAMP", 1);
+        // TFQMRGPU_DEEP=1 (lab builds): four operand sets for 32 x 32 float (measured on config 3: plain multiply 90.8 -> 94.8 TFLOP/s, but the
+        // fused kernel with its epilogue prefetch spills: 0.317 -> 0.350 ms) -- off
+        static int const use_deep = lab_switch("TFQMRGPU_DEEP", 0);
         auto go = [&](auto M3c, auto Hc) {
             constexpr bool M3 = decltype(M3c)::value, H = decltype(Hc)::value;
             if constexpr (canClamp) if (use_clamp) {
@@ -1572,7 +1580,7 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
         } else { if (m3) go(T{}, F{}); else go(F{}, F{}); }
     } else if constexpr (kTile8<R, LM, LN>) {
         constexpr bool pre8 = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
-        static int const use_pre8 = [] { auto v = std::getenv("TFQMRGPU_EPI_PREFETCH"); return v ? std::atoi(v) : 1; }();
+        static int const use_pre8 = lab_switch("TFQMRGPU_EPI_PREFETCH", 1);
         if (pre8 && use_pre8) k_spmm_mfma8<R, LM, LN, EPI, pre8><<<dim3(nWG), dim3(256), 0, s>>>(a);
         else k_spmm_mfma8<R, LM, LN, EPI, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
     }
@@ -1607,7 +1615,8 @@ static SpmmArgs spmm_args(int epi, DevPlan const& d) {
     a.A = d.A; a.starts = d.starts; a.pairs = d.pairs; a.nY = d.nnzbX;
     a.chunkFirst = d.chunkFirst; a.chunkCol = d.chunkCol; a.CH = 0;
     a.order = d.order;
-    a.ctl = d.ctl; a.v3 = d.v3; a.B = d.B; a.bOfX = d.bOfX; a.pz = d.pz; a.pd = d.pd;
+    a.ctl = d.ctl; a.v3 = d.v3; a.B = d.R ? d.R : d.B; a.bOfX = d.R ? nullptr : d.bOfX; a.pz = d.pz; a.pd = d.pd;
+    a.m3 = d.m3;
     a.hashV3 = d.hashV3; a.origCol = d.origCol; a.rowI = d.rowI; a.ilv = d.ilv; a.aOnce = d.aOnce;
     switch (epi) {
     case EPI_XPAY_DOT:     a.X = d.v6; a.Y = d.v9; a.e0 = d.v4; a.e1 = d.v8; a.sc = d.beta; a.gate = 1; a.first = d.first; break;

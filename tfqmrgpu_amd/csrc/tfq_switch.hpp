@@ -1,0 +1,18 @@
+// Tuning switches.  The product's dispatch is FROZEN: every switch has the value that was measured best and
+// nothing in libtfQMRgpu.so reads the environment to choose a kernel or a layout.  A lab build (libtfQMRgpu_lab.so, the same
+// sources compiled with -DTFQ_LAB by the Makefile) reads TFQMRGPU_* from the environment instead, for A/B runs of whole builds and
+// for the tests that drive every non-default code path (tests/test_gpu_hash_mode.py).
+#pragma once
+#include <cstdlib>
+
+namespace tfq {
+inline int lab_switch(char const* name, int dflt) {
+#ifdef TFQ_LAB
+    auto const v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+} // namespace tfq

@@ -141,6 +141,11 @@ __device__ inline void chunk_reduce(double (&acc)[NPL][VEC], double* s, double* 
 // take the B block under an X block (bOfX), or zeros, directly -- v5 itself is first WRITTEN by k_v5_nrm of that iteration.
 template <typename R, int VEC>
 __device__ inline void ld_rhs(R (&r)[VEC], R (&i)[VEC], DevPlan const& d, uint32_t xblock, size_t inner, int P) {
+    if (d.R) {   // the right-hand side of this solve is a whole X-shaped vector (mixed-precision refinement)
+        R const* b = (R const*)d.R + size_t(xblock) * 2 * P + inner;
+        ldv(r, b); ldv(i, b + P);
+        return;
+    }
     uint32_t const bq = d.bOfX[xblock];
     if (0xffffffffu == bq) {
 #pragma unroll
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256) void k_dot35(DevPlan d) {
     double acc[2][G::VEC] = {};
     if (t < G::T) for (uint32_t w = t; w < nItems; w += G::T) {
         TFQ_ITEM_OFFSETS(G)
-        if (0xffffffffu == d.bOfX[first + blk]) continue;   // v5 = B scattered onto zeros: only blocks under a B block count
+        if (!d.R && 0xffffffffu == d.bOfX[first + blk]) continue;   // v5 = B scattered onto zeros: only blocks under a B block count
         R ar[G::VEC], ai[G::VEC]; float wr[G::VEC], wi[G::VEC];
         ld_rhs<R, G::VEC>(ar, ai, d, first + blk, size_t(w - blk * G::IPB) * G::VEC, G::P); ldf(wr, d.v3 + re); ldf(wi, d.v3 + im);
 #pragma unroll
@@ -495,13 +500,15 @@ __global__ __launch_bounds__(256) void k_decide(DevPlan d, int what, int phase) 
     } else {
         double max_res2 = 1.4e-76;
         if (c->red[3] > max_res2) max_res2 = c->red[3];
-        c->residual2_reached = max_res2;
         c->target_bound2 = (c->max_bound2 / max_res2) * c->tol2;
         c->nprobes += 1;
         c->probe = 0;
         c->xpend = 0;   // k_x_flush has brought x up to date
+        double const before = c->residual2_reached;      // of the previous probe of this solve (1e300 at the start)
+        c->residual2_reached = max_res2;
         if (c->red[4] == 0.) { c->iterations_needed = c->iteration; c->state = 1; }
         else if (c->iteration >= c->maxIterations) c->state = 3;
+        else if (c->stallStop && max_res2 > 0.49 * before) c->state = 3;   // |r| no better than 0.7 x the previous probe's: the float floor
     }
 }
 
@@ -543,7 +550,122 @@ __global__ __launch_bounds__(256) void k_init_col(DevPlan d, double tol, int max
         for (int i = 0; i < 6; ++i) c->red[i] = 0;
         c->iteration = 0; c->maxIterations = maxIterations;
         c->state = (maxIterations > 0) ? 0 : 3;
-        c->probe = 0; c->iterations_needed = maxIterations; c->nprobes = 0; c->xpend = 0;
+        c->probe = 0; c->iterations_needed = maxIterations; c->nprobes = 0; c->xpend = 0; c->stallStop = 0;
+    }
+}
+
+// ---- mixed precision 'm': the refinement around the float solves ---------------------------------------------------
+// The reference sketches the mode as float storage with double multiply-accumulate (tfqmrgpu.cu:42, commented out) and documents it
+// as "start with float and converge double" (tfqmrgpu.h:72).  Here: classical iterative refinement.  x, B and A are kept in
+// double; every cycle computes r = b - A x in double, solves A d = r with the complex<float> tfQMR (all of its kernels unchanged,
+// the right-hand side is the X-shaped vector R instead of B under X) and adds d to x in double.  The float iteration moves half the
+// bytes of the double one and every cycle gains the digits a float solve can deliver (4-5), so the result converges to the double
+// threshold at float bandwidth.
+
+// threads t < T handle the elements w = t, t + T, ... of a chunk in the LOGICAL order [block][Re|Im][row][column]; T is a multiple of
+// LN, so a thread keeps its column (right-hand side) j = t % LN
+template <int LM, int LN>
+__global__ __launch_bounds__(256) void k_refine_residual(RefineArgs a) {
+    constexpr int P = LM * LN, T = (256 / LN) * LN;
+    __shared__ double s[256];
+    DevPlan const& d = a.d;
+    int const t = threadIdx.x;
+    uint32_t const chunk = blockIdx.x;
+    uint32_t const first = d.chunkFirst[chunk], last = d.chunkFirst[chunk + 1];
+    double acc = 0;
+    float* const R = (float*)d.R;
+    if (t < T) for (uint32_t w = t; w < (last - first) * 2 * P; w += T) {
+        uint32_t const blk = first + w / (2 * P);
+        int const e = int(w % (2 * P)), c = e / P, r = (e % P) / LN, q = e % LN;
+        size_t const zoff = size_t(c) * P + plane_offset(a.ilvZ, r, q, LN);
+        uint32_t const bq = d.bOfX[blk];
+        double v = (0xffffffffu == bq) ? 0. : a.Bz[size_t(bq) * 2 * P + zoff];
+        if (a.cycle > 0) v -= a.Yz[size_t(blk) * 2 * P + zoff];
+        acc = __builtin_fma(v, v, acc);
+        R[size_t(blk) * 2 * P + size_t(c) * P + plane_offset(d.ilv, r, q, LN)] = float(v);
+    }
+    s[t] = (t < T) ? acc : 0.;
+    __syncthreads();
+    if (t < LN) {
+        double sum = 0;
+        for (int u = t; u < T; u += LN) sum += s[u];
+        d.pd[size_t(chunk) * LN + t] = sum;
+    }
+}
+
+// per block column: |r|^2 per right-hand side from the chunk records -> the set-up of the inner solve (what k_init_col does from B:
+// tau = |r|^2, 1 / |r|^2, rho = 1, everything else 0) and max_rhs |r|^2 / |b|^2 for the refinement's own stopping test
+template <int LN>
+__global__ __launch_bounds__(256) void k_refine_init_col(RefineArgs a) {
+    using R = float;
+    __shared__ double s[256];
+    __shared__ double rec[LN];
+    DevPlan const& d = a.d;
+    uint32_t const col = blockIdx.x;
+    double dd[1];
+    column_sum<LN, 1>(d.pd, d.colChunkPtr[col], d.colChunkPtr[col + 1], s, dd);
+    int const t = threadIdx.x;
+    if (t < LN) {
+        double const n2 = dd[0];
+        size_t const ir = (size_t(col) * 2 + 0) * LN + t, ii = ir + LN, i1 = size_t(col) * LN + t;
+        if (0 == a.cycle) a.bn2z[i1] = n2;
+        double const b2 = a.bn2z[i1];
+        rec[t] = (b2 > 0.) ? n2 / b2 : 0.;      // a right-hand side that is zero is solved by x = 0
+        d.tau[i1] = n2; d.invBn2[i1] = 1. / n2; d.var[i1] = 0; d.d[i1] = 0; d.status[i1] = 0;
+        ((R*)d.rho)[ir] = 1; ((R*)d.rho)[ii] = 0;
+        ((R*)d.alfa)[ir] = 0; ((R*)d.alfa)[ii] = 0; ((R*)d.beta)[ir] = 0; ((R*)d.beta)[ii] = 0;
+        ((R*)d.c67)[ir] = 0; ((R*)d.c67)[ii] = 0; ((R*)d.eta)[ir] = 0; ((R*)d.eta)[ii] = 0;
+        ((R*)d.c67a)[ir] = 0; ((R*)d.c67a)[ii] = 0; ((R*)d.eta2)[ir] = 0; ((R*)d.eta2)[ii] = 0;
+    }
+    __syncthreads();
+    if (0 == t) {
+        double mx = 0, bad = 0;
+        for (int j = 0; j < LN; ++j) { if (rec[j] > mx) mx = rec[j]; if (!(rec[j] == rec[j]) || rec[j] > 1e300) bad = 1; }
+        d.colrec[size_t(col) * 2 + 0] = mx; d.colrec[size_t(col) * 2 + 1] = bad;
+    }
+    if (0 == col && 0 == t) {
+        Ctl* c = d.ctl;
+        double const tol2 = a.innerTol * a.innerTol;
+        c->tol2 = tol2; c->target_bound2 = tol2 * 100 * 100; c->max_bound2 = 0; c->residual2_reached = 1e300;
+        for (int i = 0; i < 6; ++i) c->red[i] = 0;
+        c->iteration = 0; c->maxIterations = a.innerMaxIt;
+        c->state = (a.innerMaxIt > 0) ? 0 : 3;
+        c->probe = 0; c->iterations_needed = a.innerMaxIt; c->nprobes = 0; c->xpend = 0; c->stallStop = 1;
+    }
+}
+
+// max over the block columns -> refine[0], refine[1] (refine[2], "a rank failed", is the host's)
+__global__ __launch_bounds__(256) void k_refine_max(RefineArgs a) {
+    __shared__ double s0[256], s1[256];
+    int const t = threadIdx.x;
+    double u = 0, v = 0;
+    for (uint32_t col = t; col < a.d.nCols; col += 256) {
+        double const x = a.d.colrec[size_t(col) * 2], y = a.d.colrec[size_t(col) * 2 + 1];
+        if (x > u) u = x; if (y > v) v = y;
+    }
+    s0[t] = u; s1[t] = v;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if (t < h) { if (s0[t + h] > s0[t]) s0[t] = s0[t + h]; if (s1[t + h] > s1[t]) s1[t] = s1[t + h]; }
+        __syncthreads();
+    }
+    if (0 == t) { a.refine[0] = s0[0]; a.refine[1] = s1[0]; a.refine[2] = 0; }
+}
+
+// x (double) += d (the float solution of the inner solve); cycle 0: x = d (x is not read: nothing has to be cleared)
+template <int LM, int LN>
+__global__ __launch_bounds__(256) void k_refine_update(RefineArgs a) {
+    constexpr int P = LM * LN;
+    DevPlan const& d = a.d;
+    uint32_t const chunk = blockIdx.x;
+    uint32_t const first = d.chunkFirst[chunk], last = d.chunkFirst[chunk + 1];
+    float const* const xc = (float const*)d.x;
+    for (uint32_t w = threadIdx.x; w < (last - first) * 2 * P; w += 256) {
+        uint32_t const blk = first + w / (2 * P);
+        int const e = int(w % (2 * P)), c = e / P, r = (e % P) / LN, q = e % LN;
+        double* const xz = a.xz + size_t(blk) * 2 * P + size_t(c) * P + plane_offset(a.ilvZ, r, q, LN);
+        double const dx = double(xc[size_t(blk) * 2 * P + size_t(c) * P + plane_offset(d.ilv, r, q, LN)]);
+        *xz = (a.cycle > 0) ? *xz + dx : dx;
     }
 }
 
@@ -562,7 +684,7 @@ static hipError_t vec_run(int op, DevPlan const& d, double tol, int maxIt, hipSt
         // kernels take that as given instead of reading it (DevPlan::first); v9 is written before it is read.
         // No iteration at all: x is the answer, zero.
         if (maxIt <= 0) if (auto const e = hipMemsetAsync(d.x, 0, S, s)) return e;
-        k_init_col<R, LM, LN><<<cols, blk, 0, s>>>(d, tol, maxIt);
+        if (!d.R) k_init_col<R, LM, LN><<<cols, blk, 0, s>>>(d, tol, maxIt);   // (R: set up by k_refine_init_col, with |r|^2 from its own records)
         k_dot35<R, LM, LN><<<grid, blk, 0, s>>>(d);
     } break;
     case VEC_DEC35:    k_dec35<R, LN><<<cols, blk, 0, s>>>(d); break;
@@ -586,6 +708,24 @@ hipError_t vec_launch(int op, DevPlan const& d, double tol, int maxIt, hipStream
 #undef TFQ_CASE
     return hipErrorInvalidValue;
 }
+
+template <int LM, int LN>
+static void refine_run(int what, RefineArgs const& a, hipStream_t s) {
+    dim3 const grid(a.d.nChunks), cols(a.d.nCols), blk(256);
+    if (0 == what) {
+        k_refine_residual<LM, LN><<<grid, blk, 0, s>>>(a);
+        k_refine_init_col<LN><<<cols, blk, 0, s>>>(a);
+        k_refine_max<<<1, blk, 0, s>>>(a);
+    } else k_refine_update<LM, LN><<<grid, blk, 0, s>>>(a);
+}
+static void refine_dispatch(int what, RefineArgs const& a, hipStream_t s) {
+    int const key = a.d.LM * 1000 + a.d.LN;
+#define TFQ_CASE(R, LM, LN) case LM * 1000 + LN: refine_run<LM, LN>(what, a, s); break;
+    switch (key) { TFQ_SIZES(TFQ_CASE, float) default: break; }
+#undef TFQ_CASE
+}
+void launch_refine_residual(RefineArgs const& a, hipStream_t s) { refine_dispatch(0, a, s); }
+void launch_refine_update(RefineArgs const& a, hipStream_t s)   { refine_dispatch(1, a, s); }
 
 void launch_decide(DevPlan const& d, int phase, hipStream_t s)       { k_decide<<<1, 256, 0, s>>>(d, 0, phase); }
 void launch_probe_decide(DevPlan const& d, int phase, hipStream_t s) { k_decide<<<1, 256, 0, s>>>(d, 1, phase); }
