@@ -406,6 +406,31 @@ def main():
                 s1.close()
                 del buf1
 
+            # "same A, new B, solve again" (README.md:97-104 of the reference) with B and X resident on the device: setMatrix('B') + solve +
+            # getMatrix('X') per right-hand side, the arrays converted in place by the library (no staging, no PCIe)
+            ctype = torch.complex128 if prec == "z" else torch.complex64
+            s.data_precision = prec
+            dB = torch.from_numpy(pr.B).to(ctype).cuda()
+            dXout = torch.empty((pr.nnzbX, pr.LM, pr.LN), dtype=ctype, device="cuda")
+            torch.cuda.synchronize()
+            tr0 = time.perf_counter()
+            for _ in range(args.steps):
+                s.set_matrix_device("B", dB.data_ptr())
+                s.solve(pr.tolerance, args.max_iterations)
+                s.get_matrix_device(dXout.data_ptr())
+            torch.cuda.synchronize()
+            resolve_ms = (time.perf_counter() - tr0) / args.steps * 1e3
+            th0 = time.perf_counter()
+            s.set_matrix("B", pr.B)
+            s.solve(pr.tolerance, args.max_iterations)
+            Xh = s.get_matrix()
+            resolve_host_ms = (time.perf_counter() - th0) * 1e3
+            resolve = dict(resolve_ms=round(resolve_ms, 3), over_solve=round(resolve_ms / (elapsed / args.steps * 1e3), 3),
+                           resolve_host_arrays_ms=round(resolve_host_ms, 1),
+                           note="setMatrix('B') + solve + getMatrix('X'); resolve_ms: B and X in device memory (converted in place by the library), "
+                                "resolve_host_arrays_ms: pageable host arrays (X = %.0f MB over PCIe)" % (S_bytes(pr, prec) / 1e6))
+            del dB, dXout, Xh
+
             # the same system in mixed precision (bufferSize 'm': complex<float> tfQMR inside a refinement in double):
             # time to the SAME threshold in double arithmetic, beside the headline figure (which stays the complex<double> solve)
             mixed = None
@@ -432,6 +457,7 @@ def main():
                 it_m = sum((pm[k][1] - pf[k][1]) / max(1, pm[k][0] - pf[k][0]) for k in pm if k != "probe")
                 mixed = dict(ms_per_solve=round(tm * 1e3, 3), solve_status=int(stm), float_iterations=im["iterations"], residual=im["residual"],
                              refinement_residuals=[float("%.3e" % v) for v in sm.refinement_history()],
+                             float_iterations_per_cycle=[int(v) for v in sm.refinement_history(True)[1][:-1]],
                              ms_per_float_iteration=round(it_m, 4), buffer_GB=round(mbytes / 1e9, 3),
                              speedup_vs_double=round(elapsed / args.steps / tm, 3),
                              note="same threshold (max_rhs |b - A x| / |b| <= %g in double arithmetic), same system; not the headline metric" % pr.tolerance)
@@ -464,6 +490,7 @@ def main():
                 "roofline_multiply_native_api": rmn,
                 "roofline_multiply_hbm_bound": rh,
                 "mixed_precision": mixed,
+                "resolve": resolve,
                 "roofline_iteration": dict(bound="hbm", achieved=round(it_bytes / (it_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                                            frac=round(it_bytes / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), ms_per_iteration=round(it_ms, 4),
                                            algorithmic_bytes=int(it_bytes)),

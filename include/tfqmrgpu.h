@@ -104,7 +104,10 @@ tfqmrgpuStatus_t tfqmrgpu_bsrsv_bufferSize(tfqmrgpuHandle_t handle,
 tfqmrgpuStatus_t tfqmrgpu_bsrsv_setBuffer(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, void* const pBuffer);
 tfqmrgpuStatus_t tfqmrgpu_bsrsv_getBuffer(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t plan, void* *pBuffer);
 
-/* upload block values of 'A', 'B' (or 'X'); reference tfqmrgpu.h:87-95 */
+/* upload block values of 'A', 'B' (or 'X'); reference tfqmrgpu.h:87-95.
+ * `val` may also be DEVICE memory (hipMalloc / hipMallocManaged; setMatrix and getMatrix alike): the blocks are then converted
+ * straight from / into the caller's array by one kernel on the handle's stream, without staging and without crossing PCIe --
+ * the call returns when the kernel is enqueued, the array must stay valid until the stream has passed it. */
 tfqmrgpuStatus_t tfqmrgpu_bsrsv_setMatrix(tfqmrgpuHandle_t handle,
     tfqmrgpuBsrsvPlan_t plan,
     char const var,              /* 'A', 'B' or 'X'                                        */

@@ -152,8 +152,9 @@ tfqmrgpuStatus_t tfqmrgpuExt_setReduceCallback(tfqmrgpuHandle_t handle, tfqmrgpu
  * max_rhs |b - A x| / |b| in double arithmetic, maxIterations bounds the sum of the float iterations; getInfo reports that sum.
  * The buffer is 11 float-sized vectors against 15 for 'z'.  Where float iterations cannot reduce the residual (systems on which
  * the 'c' solver stagnates above ~0.1) solve returns TFQMRGPU_STATUS_MAX_ITERATIONS with the best x.
- * getRefinementHistory: the relative residual (double arithmetic) in front of every float solve and at the end; returns the count. */
-int32_t tfqmrgpuExt_getRefinementHistory(tfqmrgpuBsrsvPlan_t plan, double *residual, int32_t capacity);
+ * getRefinementHistory: residual[i] = the relative residual (double arithmetic) in front of float solve i, the last entry the final
+ * one; iterations[i] = the float iterations of solve i (0 in the last entry); either array may be NULL; returns the count. */
+int32_t tfqmrgpuExt_getRefinementHistory(tfqmrgpuBsrsvPlan_t plan, double *residual, int32_t *iterations, int32_t capacity);
 /* Three real products per complex one (Gauss) in the complex<double> multiplies of the block shapes above 16 x 16: a quarter fewer
  * matrix instructions (64 x 64: iteration -7 %), but Im = P3 - P1 - P2 is accurate relative to |A||X| only -- an imaginary part
  * 10^-k times smaller than the real part loses k digits against the reference's four products.  OFF unless switched on here

@@ -1,6 +1,8 @@
 """TEST INFRASTRUCTURE -- ctypes access to the CPU oracle (oracle/liboracle.so, this repo's plain-C
 restatement) and, where it was built, to the reference itself (oracle/_ref/, compiled from
-/root/reference by oracle/Makefile; exists only in the build container, never on the GPU box).
+/root/reference by oracle/Makefile: buildable only where the reference's sources are, i.e. in the build container; the
+BUILT files are git-ignored but travel with gpurun snapshots, so that bench.py's cpu_baseline leg can time the reference's own
+CPU library on the GPU box's host cores -- DESIGN.md section 5).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this module.
 """

@@ -24,7 +24,11 @@ def main():
     import tfqmrgpu_amd as T
     from conftest import load_problem
     from oracle import pyoracle as O
-    pr = load_problem(name)
+    if name.startswith("cfg4:"):     # BASELINE config 4's pattern (bench.py --workload cfg4) at a reduced grid: cfg4:nx:ncols
+        from bench import build_problem
+        pr = build_problem(name, 0, 1)[0]
+    else:
+        pr = load_problem(name)
     sub, xb, bb = T.shard_columns(pr, world, rank)
     E = 2 * pr.LM * pr.LN
     v3 = O.shadow_glibc(pr.nnzbX * E).reshape(pr.nnzbX, E)[xb].reshape(-1)

@@ -123,7 +123,8 @@ def test_recomputing_the_shadow_vector_changes_no_bit(tmp_path, name, prec, tol)
 SWITCHES = [dict(TFQMRGPU_3M=1), dict(TFQMRGPU_3M=2), dict(TFQMRGPU_EPI_PREFETCH=0), dict(TFQMRGPU_ORDER=0),
             dict(TFQMRGPU_DEPTH=1), dict(TFQMRGPU_DEPTH=4), dict(TFQMRGPU_CHUNK_KIB=64), dict(TFQMRGPU_ORDER_G=8),
             dict(TFQMRGPU_ILV=0),     # ILV=0: 16 x 16 and 8 x 8 z plans keep the native element order (k_spmm_mfma / k_spmm_mfma8)
-            dict(TFQMRGPU_A_STREAM=0), dict(TFQMRGPU_CLAMP=0)]
+            dict(TFQMRGPU_A_STREAM=0), dict(TFQMRGPU_CLAMP=0),
+            dict(TFQMRGPU_FOLD_MAX=0)]   # the column operations as launches of their own (these small systems fold them into the producers' tails)
 
 
 @pytest.mark.parametrize("name,prec,tol", [("stencil:16:16:16:16:4:7:5", "z", 1e-9), ("stencil:8:8:32:32:2:3:13", "z", 1e-9),
@@ -141,7 +142,7 @@ def test_tuning_switches_change_code_paths_not_results(tmp_path, name, prec, tol
         assert int(got["status"]) == 0 and int(got["iterations"]) == int(base["iterations"]), sw
         assert np.allclose(got["history"], base["history"], rtol=1e-6, atol=0), sw
         assert np.abs(got["X"] - base["X"]).max() <= 1e-9 * np.abs(base["X"]).max(), sw
-        if "TFQMRGPU_DEPTH" in sw or "TFQMRGPU_ORDER" in sw or "TFQMRGPU_ORDER_G" in sw or "TFQMRGPU_A_STREAM" in sw:
+        if "TFQMRGPU_DEPTH" in sw or "TFQMRGPU_ORDER" in sw or "TFQMRGPU_ORDER_G" in sw or "TFQMRGPU_A_STREAM" in sw or "TFQMRGPU_FOLD_MAX" in sw:
             assert np.array_equal(got["X"], base["X"]), sw   # these change WHEN things run, never what is added to what
 
 

@@ -142,6 +142,40 @@ def test_set_get_matrix_layouts(prec, shape):
                         assert np.array_equal(got, want), (lay_in, tr_in, lay_out, tr_out)
 
 
+@pytest.mark.parametrize("prec", ["z", "c", "m"])
+def test_set_get_matrix_take_device_arrays(torch_cuda, prec):
+    """setMatrix / getMatrix with arrays in DEVICE memory (include/tfqmrgpu.h): converted in place of the caller's array on the stream,
+    same result as with host arrays -- the "same A, new B, solve again" loop without a PCIe crossing"""
+    torch = torch_cuda
+    pr = PR.stencil_2d(6, 5, 16, 16, 3, seed=21)
+    ctype = torch.complex64 if prec == "c" else torch.complex128
+    with T.Solver() as s:
+        s.create_plan(pr)
+        s.set_buffer(nbytes=s.buffer_size(16, 16, prec))
+        s.set_matrix("A", pr.A); s.set_matrix("B", pr.B)
+        tol = 1e-4 if prec == "c" else 1e-9
+        assert s.solve(tol, 200) == 0
+        X_host = s.get_matrix()
+        dA = torch.from_numpy(pr.A).to(ctype).cuda()
+        dB = torch.from_numpy(pr.B).to(ctype).cuda()
+        dX = torch.zeros((pr.nnzbX, 16, 16), dtype=ctype, device="cuda")
+        s.set_matrix_device("A", dA.data_ptr())
+        s.set_matrix_device("B", dB.data_ptr())
+        assert s.solve(tol, 200) == 0
+        s.get_matrix_device(dX.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(dX.cpu().numpy(), X_host)
+        for trans in "tc":                                     # the layout / transposition machinery is the same kernel
+            s.get_matrix_device(dX.data_ptr(), trans=trans)
+            torch.cuda.synchronize()
+            assert np.array_equal(dX.cpu().numpy().reshape(pr.nnzbX, -1), s.get_matrix(trans=trans).reshape(pr.nnzbX, -1))
+        s.set_matrix_device("B", (2 * dB).data_ptr())           # new right-hand side, resident on the device
+        assert s.solve(tol, 200) == 0
+        s.get_matrix_device(dX.data_ptr())
+        torch.cuda.synchronize()
+        assert np.abs(dX.cpu().numpy() - 2 * X_host).max() <= (1e-3 if prec == "c" else 1e-7) * np.abs(X_host).max()
+
+
 def _rand_pairs(rng, nY, nA, nX, maxp):
     starts, pairs = [0], []
     for _ in range(nY):

@@ -97,7 +97,7 @@ def test_glibc_rand_restatement(oracle):
 
 def test_against_live_reference(oracle):
     if not oracle.have_ref():
-        pytest.skip("oracle/_ref not built (the reference exists only in the build container)")
+        pytest.skip("oracle/_ref not present (it can only be built where /root/reference exists; the built files travel with gpurun snapshots)")
     ref = oracle.Reference()
     pr = PR.stencil_2d(5, 5, 4, 8, 3, seed=77, radius=2.0)
     a, r = oracle.analyse(pr), ref.analyse(pr)

@@ -129,7 +129,7 @@ def load_library(path=LIB_PATH):
     lib.tfqmrgpuExt_commDestroy.argtypes = [P]
     lib.tfqmrgpuExt_setReduceCallback.argtypes = [P, REDUCE_CB, P]
     lib.tfqmrgpuExt_setOperator.argtypes = [P, OPERATOR_CB, P]
-    lib.tfqmrgpuExt_getRefinementHistory.argtypes = [P, P, C.c_int32]
+    lib.tfqmrgpuExt_getRefinementHistory.argtypes = [P, P, P, C.c_int32]
     lib.tfqmrgpuExt_setThreeProductMultiply.argtypes = [P, I]
     return lib
 
@@ -270,6 +270,18 @@ class Solver:
                                           self.LN if var in "XBxb" else self.LM, self.LM, trans.encode(), layout)
         return _check(st, "tfqmrgpu_bsrsv_setMatrix('%s')" % var)
 
+    def set_matrix_device(self, var, device_ptr, trans="n", layout=LAYOUT_RIRIRIRI):
+        """the same call with an array that lives in DEVICE memory (data_precision says float or double): the library converts
+        straight from it, asynchronously on the handle's stream"""
+        st = lib.tfqmrgpu_bsrsv_setMatrix(self.handle, self.plan, var.encode(), C.c_void_p(device_ptr), self.data_precision.encode(),
+                                          self.LN if var in "XBxb" else self.LM, self.LM, trans.encode(), layout)
+        return _check(st, "tfqmrgpu_bsrsv_setMatrix('%s', device array)" % var)
+
+    def get_matrix_device(self, device_ptr, trans="n", layout=LAYOUT_RIRIRIRI):
+        st = lib.tfqmrgpu_bsrsv_getMatrix(self.handle, self.plan, b"X", C.c_void_p(device_ptr), self.data_precision.encode(),
+                                          self.LN, self.LM, trans.encode(), layout)
+        return _check(st, "tfqmrgpu_bsrsv_getMatrix(device array)")
+
     def get_matrix(self, nnzb=None, trans="n", layout=LAYOUT_RIRIRIRI, raw=False):
         nnzb = self.problem.nnzbX if nnzb is None else nnzb
         out = np.zeros((nnzb, self.LM, self.LN, 2), dtype=self._real_dtype())
@@ -314,13 +326,14 @@ class Solver:
                "tfqmrgpu_bsrsv_getInfo")
         return dict(residual=r.value, iterations=it.value, flops=f.value, flops_all=fa.value)
 
-    def refinement_history(self):
-        """mixed precision: relative residual (double arithmetic) in front of every float solve and at the end"""
-        n = lib.tfqmrgpuExt_getRefinementHistory(self.plan, None, 0)
-        h = np.zeros(max(n, 0), dtype=np.float64)
+    def refinement_history(self, with_iterations=False):
+        """mixed precision: relative residual (double arithmetic) in front of every float solve and at the end
+        [, the float iterations of every solve]"""
+        n = lib.tfqmrgpuExt_getRefinementHistory(self.plan, None, None, 0)
+        h, it = np.zeros(max(n, 0), dtype=np.float64), np.zeros(max(n, 0), dtype=np.int32)
         if n > 0:
-            lib.tfqmrgpuExt_getRefinementHistory(self.plan, _ptr(h), n)
-        return h
+            lib.tfqmrgpuExt_getRefinementHistory(self.plan, _ptr(h), _ptr(it), n)
+        return (h, it) if with_iterations else h
 
     def set_three_product_multiply(self, on=True):
         _check(lib.tfqmrgpuExt_setThreeProductMultiply(self.plan, int(on)), "tfqmrgpuExt_setThreeProductMultiply")

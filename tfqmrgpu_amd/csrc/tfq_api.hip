@@ -33,6 +33,7 @@ DevPlan resolve(Plan const& p) {
     static int const antEnv = lab_switch("TFQMRGPU_A_STREAM", 1);
     d.aOnce = (p.aOnce && antEnv) ? 1 : 0;   // (lab builds, TFQMRGPU_A_STREAM=0: A operands always through the caches)
     d.m3 = p.threeProducts ? 1 : 0;
+    d.fold = 0; d.foldCount = (uint32_t*)at(p.wFold); d.self = (DevPlan const*)at(p.wSelf);
     d.R = ('m' == p.precision) ? at(p.wR) : nullptr;
     d.x = at(p.wX); d.v4 = at(p.wV4); d.v5 = at(p.wV5); d.v6 = at(p.wV6); d.v7 = at(p.wV7);
     d.v8 = at(p.wV8); d.v9 = at(p.wV9); d.B = at(p.wB); d.A = at(p.wA); d.v3 = (float*)at(p.wV3);
@@ -98,10 +99,26 @@ static Stage stage_of(Plan const& p) {
 // nativeDbl / ilv: precision and element order of the library's; `also`: a second library-side copy of the same blocks (the float A of a
 // mixed-precision plan next to its double A)
 struct Target { void* native; bool dbl; int ilv; };
+
+// is `ptr` memory the GPU can read and write directly (hipMalloc, hipMallocManaged)?  Then setMatrix / getMatrix convert in place
+// of the caller's array, no staging and no PCIe: the "same A, new B, solve again" loop of a caller whose B and X live on the
+// device (README.md:97-104 of the reference asks for plan reuse; with host arrays X alone is 0.1 s of copies per 35 ms solve on P2).
+static bool on_device(void const* ptr) {
+    hipPointerAttribute_t a{};
+    if (hipSuccess != hipPointerGetAttributes(&a, ptr)) { (void)hipGetLastError(); return false; }   // plain host memory: not an error of the caller
+    return hipMemoryTypeDevice == a.type || hipMemoryTypeManaged == a.type || a.isManaged;
+}
+
 static tfqmrgpuStatus_t transfer_blocks(Plan& p, hipStream_t s, int direction, bool userDbl, Target const& to,
     void* host, uint32_t const* u2n, uint32_t nBlocks, int nR, int nC, int layout, bool trans, bool conj, Stage const* own = nullptr,
     Target const* also = nullptr)
 {
+    if (on_device(host)) {   // the caller's array is device memory: one conversion kernel straight from / into it, asynchronous on the stream
+        launch_convert(direction, userDbl, to.dbl, to.native, host, u2n, 0, nBlocks, nR, nC, layout, trans, conj, to.ilv, s);
+        if (also && 0 == direction) launch_convert(0, userDbl, also->dbl, also->native, host, u2n, 0, nBlocks, nR, nC, layout, trans, conj, also->ilv, s);
+        TFQ_HIP(hipGetLastError(), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        return TFQMRGPU_STATUS_SUCCESS;
+    }
     Stage const st = own ? *own : stage_of(p);
     size_t const blockBytes = size_t(2) * nR * nC * (userDbl ? 8 : 4);
     size_t const cap = st.bytes / blockBytes;
@@ -220,9 +237,13 @@ static Roctx const& roctx() { static Roctx const r; return r; }
 // by the refinement, tfq_vec.hip); `early`: a refusal the caller has found already (it still has to travel through the ranks' vote);
 // every bound of the history is multiplied by histScale (a refinement cycle's bounds are relative to ITS right-hand side).
 struct SolveOutcome { Ctl last; double userFlops = 0; };
-static tfqmrgpuStatus_t run_tfqmr(Handle& h, Plan& p, DevPlan const& d, double tol, int maxIt, tfqmrgpuStatus_t early, double histScale, SolveOutcome& out) {
+static tfqmrgpuStatus_t run_tfqmr(Handle& h, Plan& p, DevPlan const& dIn, double tol, int maxIt, tfqmrgpuStatus_t early, double histScale, SolveOutcome& out) {
     hipStream_t const s = (hipStream_t)h.stream;
     bool const multi = (h.comm != nullptr) || (h.reduceFn != nullptr);
+    // small systems: the column operations and the decisions run in the producers' tails (one rank, built-in operator: a reduction
+    // over ranks or a foreign multiply sits between the producer and the decision otherwise)
+    bool const fold = p.foldOk && !multi && !p.opFn;
+    DevPlan const d = [&] { DevPlan x = dIn; x.fold = fold ? 1 : 0; return x; }();
     constexpr int DEPTH = Plan::kDepth;
     constexpr int NK = TFQMRGPU_PROFILE_CLASSES;
     // How far the host runs ahead: 2 slots.  Every slot that is still queued when the solve stops costs ~14 empty
@@ -326,29 +347,30 @@ static tfqmrgpuStatus_t run_tfqmr(Handle& h, Plan& p, DevPlan const& d, double t
             mark(TFQMRGPU_PROF_DEC35);            (void)vec_launch(VEC_DEC35, d, 0, 0, s);
             mark(TFQMRGPU_PROF_XPAY_V6);          (void)vec_launch(VEC_XPAY_V6, dSlot, 0, 0, s);
             mark(TFQMRGPU_PROF_SPMM_V4_DOT);      multiply(EPI_XPAY_DOT, dSlot);
-            mark(TFQMRGPU_PROF_DEC34);            (void)vec_launch(VEC_DEC34, d, 0, 0, s);
+            // (fold: dec34, decT, decT + decide and the probe's column records + decision run in the tails of the kernels in front of them)
+            mark(TFQMRGPU_PROF_DEC34);            if (!fold) (void)vec_launch(VEC_DEC34, d, 0, 0, s);
             mark(TFQMRGPU_PROF_V5_NRM);           (void)vec_launch(VEC_V5_NRM, dSlot, 0, 0, s);
-            mark(TFQMRGPU_PROF_DECT_C67);         (void)vec_launch(VEC_DECT_C67, d, 0, 0, s);
+            mark(TFQMRGPU_PROF_DECT_C67);         if (!fold) (void)vec_launch(VEC_DECT_C67, d, 0, 0, s);
             mark(TFQMRGPU_PROF_X_V6_V7);          (void)vec_launch(VEC_X_V6_V7, dSlot, 0, 0, s);
             mark(TFQMRGPU_PROF_SPMM_V5_NRM_DOT);  multiply(EPI_AXPY_NRM_DOT, dSlot);
-            mark(TFQMRGPU_PROF_DECT_FINAL);       (void)vec_launch(VEC_DECT_FIN, d, 0, 0, s);
+            mark(TFQMRGPU_PROF_DECT_FINAL);       if (!fold) (void)vec_launch(VEC_DECT_FIN, d, 0, 0, s);
             mark(TFQMRGPU_PROF_DECIDE);
             if (multi) {
                 launch_decide(d, 1, s);
                 reduce(0);
                 launch_decide(d, 2, s);
-            } else launch_decide(d, 0, s);
+            } else if (!fold) launch_decide(d, 0, s);
             mark(TFQMRGPU_PROF_PROBE);
         }
         if (part != 1) {
             (void)vec_launch(VEC_X_FLUSH, d, 0, 0, s);
             multiply(EPI_RESIDUAL, dSlot);
-            (void)vec_launch(VEC_PROBE_COL, d, 0, 0, s);
+            if (!fold) (void)vec_launch(VEC_PROBE_COL, d, 0, 0, s);
             if (multi) {
                 launch_probe_decide(d, 1, s);
                 reduce(1);
                 launch_probe_decide(d, 2, s);
-            } else launch_probe_decide(d, 0, s);
+            } else if (!fold) launch_probe_decide(d, 0, s);
         }
         mark(NK);
     };
@@ -481,6 +503,7 @@ static tfqmrgpuStatus_t run_mixed(Handle& h, Plan& p, double tol, int maxIt) {
         TFQ_HIP(hipMemcpyAsync(&d.ctl->tol2, t2, sizeof t2, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
         if (auto const st = run_tfqmr(h, p, d, innerTol, maxIt - used, TFQMRGPU_STATUS_SUCCESS, res2, o)) return st;
         used += o.last.iteration;
+        p.cycleIterations.push_back(o.last.iteration);
         p.flops_performed += fm.solve(o.last) - fm.fNrm;                    // (|r|^2 of the set-up is the refinement's, counted above)
         launch_refine_update(a, s);
         p.flops_performed += 2. * p.nnzbX * p.LM * p.LN;
@@ -494,7 +517,7 @@ static tfqmrgpuStatus_t run_mixed(Handle& h, Plan& p, double tol, int maxIt) {
 
 static tfqmrgpuStatus_t run_solve(Handle& h, Plan& p, double tol, int maxIt) {
     for (int k = 0; k < TFQMRGPU_PROFILE_CLASSES; ++k) { p.profLaunches[k] = 0; p.profMs[k] = 0; p.profGatedLaunches[k] = 0; p.profGatedMs[k] = 0; p.profFirstLaunches[k] = 0; p.profFirstMs[k] = 0; }
-    p.boundHistory.clear(); p.cycleResidual.clear(); p.refinementCycles = 0;
+    p.boundHistory.clear(); p.cycleResidual.clear(); p.cycleIterations.clear(); p.refinementCycles = 0;
     p.iterations_needed = maxIt; p.flops_performed = 0;
     if ('m' == p.precision) return run_mixed(h, p, tol, maxIt);
     // what this rank can tell before it touches the device
@@ -680,8 +703,15 @@ tfqmrgpuStatus_t tfqmrgpu_bsrsv_setBuffer(tfqmrgpuHandle_t handle, tfqmrgpuBsrsv
     if ((st = up(p->wU2I, p->u2i.data(), p->u2i.size() * 4))) return st;
     if ((st = up(p->wRowI, p->rowI.data(), p->rowI.size() * 4))) return st;
     TFQ_HIP(hipMemsetAsync(at(p->wCtl), 0, p->wCtl.bytes, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+    TFQ_HIP(hipMemsetAsync(at(p->wFold), 0, p->wFold.bytes, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
     TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)     // host vectors above go out of scope
     DevPlan const d = resolve(*p);
+    {   // the device-resident copy that the folded column operations read (pointers and sizes only: nothing in it changes with a solve)
+        static_assert(sizeof(DevPlan) <= 1024, "window wSelf");
+        DevPlan self = d; self.fold = 1;
+        TFQ_HIP(hipMemcpyAsync(at(p->wSelf), &self, sizeof self, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+    }
     if (TFQMRGPU_SHADOW_GLIBC_RAND == p->shadowMode) {
         size_t const n = size_t(p->nnzbX) * 2 * p->LM * p->LN;
         std::vector<float> v3(n);
@@ -915,11 +945,14 @@ tfqmrgpuStatus_t tfqmrgpuExt_setThreeProductMultiply(tfqmrgpuBsrsvPlan_t plan, i
     return TFQMRGPU_STATUS_SUCCESS;
 }
 
-int32_t tfqmrgpuExt_getRefinementHistory(tfqmrgpuBsrsvPlan_t plan, double* residual, int32_t capacity) {
+int32_t tfqmrgpuExt_getRefinementHistory(tfqmrgpuBsrsvPlan_t plan, double* residual, int32_t* iterations, int32_t capacity) {
     auto p = asPlan(plan);
     if (!p) return -1;
     auto const n = int32_t(p->cycleResidual.size());
-    for (int32_t i = 0; i < std::min(n, capacity); ++i) if (residual) residual[i] = p->cycleResidual[i];
+    for (int32_t i = 0; i < std::min(n, capacity); ++i) {
+        if (residual) residual[i] = p->cycleResidual[i];
+        if (iterations) iterations[i] = (size_t(i) < p->cycleIterations.size()) ? p->cycleIterations[i] : 0;   // the last entry has no solve behind it
+    }
     return n;
 }
 

@@ -59,6 +59,10 @@ struct DevPlan {
                                                // mixed-precision refinement) instead of B scattered onto zeros; its |r|^2 per right-hand side
                                                // has been set up by k_refine_init_col
     int m3;                                    // three real products per complex one in the double multiplies above 16 x 16 (opt-in)
+    int fold;                                  // small systems: the column operations run in the tail of the kernel that produces their
+                                               // input (tfq_colops.hpp) instead of in launches of their own
+    uint32_t* foldCount;                       // [nCols + 1] arrival counters of that scheme (zero between uses)
+    DevPlan const* self;                       // a copy of this structure in device memory (for kernels that get SpmmArgs)
 };
 
 DevPlan resolve(Plan const& p);

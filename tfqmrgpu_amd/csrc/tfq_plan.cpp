@@ -349,6 +349,12 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     take(p.wBList, size_t(p.nnzbB) * sizeof(uint32_t));
     take(p.wU2I, size_t(p.nnzbX) * sizeof(uint32_t));
     take(p.wRowI, size_t(p.nnzbX) * sizeof(uint32_t));
+    take(p.wFold, (size_t(p.nCols) + 1) * sizeof(uint32_t));
+    take(p.wSelf, 1024);
+    // Small systems fold the column operations into the producers' tails (tfq_colops.hpp): six launches less per iteration slot.
+    // "Small" = the vectors of the whole iteration fit the L2 caches several times over, so the release / acquire of an arrival costs
+    // next to nothing (on P2, 34 522 chunks, it tripled the kernel times: round 1).  Lab builds: TFQMRGPU_FOLD_MAX chunks.
+    p.foldOk = (nChunks <= size_t(lab_switch("TFQMRGPU_FOLD_MAX", 512)));
     take(p.wA, size_t(p.nnzbA) * 2 * LM * LM * p.realBytes);
     if (mixed) {
         // Mixed precision: float vectors for the iteration (above), and in double the solution, B, A (the refinement's residual

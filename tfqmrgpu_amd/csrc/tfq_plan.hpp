@@ -88,6 +88,8 @@ struct Plan {
     // 'm' only: the solution, B and A in double; the residual of the refinement as the right-hand side of the inner (float) solve,
     // |b|^2 per right-hand side, the record of the refinement's stopping test
     Window wXz, wBz, wAz, wR, wBn2z, wRefine;
+    Window wFold, wSelf;               // arrival counters [nCols + 1] and a device copy of the DevPlan for the folded column operations
+    bool foldOk = false;               // few enough chunks that an iteration slot is launch latency: fold (tfq_colops.hpp)
 
     char* buffer = nullptr;            // device buffer registered by setBuffer
     static constexpr int kDepth = 4;   // iterations the host keeps enqueued ahead of the stopping decision
@@ -98,6 +100,7 @@ struct Plan {
     bool haveB = false;
     bool threeProducts = false;        // tfqmrgpuExt_setThreeProductMultiply: Gauss' three real products per complex one in the double multiplies
     std::vector<double> cycleResidual; // 'm': relative residual (double arithmetic) in front of every inner solve and at the end
+    std::vector<int32_t> cycleIterations; // 'm': float iterations of every inner solve
     int refinementCycles = 0;
     // user-defined operator (tfqmrgpu_ext.h section 5): callback, and library-owned device scratch
     // [xu | yu | i2u | colindx in the caller's block order]

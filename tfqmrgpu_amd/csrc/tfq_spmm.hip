@@ -34,6 +34,7 @@
 #include "tfq_device.hpp"
 #include "tfq_vec.hpp"
 #include "tfq_switch.hpp"
+#include "tfq_colops.hpp"
 
 namespace tfq {
 
@@ -57,6 +58,7 @@ struct SpmmArgs {
     int aOnce;                         // every A block is used about once per multiply (few block columns): stream A past the caches
     int first;                         // EPI_XPAY_DOT in the first iteration of a solve: old v4 = v8 = 0 by definition, not read (DevPlan::first)
     int m3;                            // double shapes above 16 x 16: three real products per complex one (tfqmrgpuExt_setThreeProductMultiply)
+    DevPlan const* foldPlan;           // not null: the column operation that consumes this launch's records runs in its tail (tfq_colops.hpp)
 };
 
 // data that a kernel touches once (epilogue vectors) moves non-temporally, so that the stream does not push the A and
@@ -161,6 +163,14 @@ __device__ inline void write_record(SpmmArgs const& a, uint32_t chunk, int LN, i
     else if constexpr (EPI == EPI_RESIDUAL) a.pd[size_t(chunk) * LN + j] = v;
 }
 
+// the column operation behind a fused multiply, run by the last work group of the column (small systems, tfq_colops.hpp)
+template <typename R, int LN, int EPI>
+__device__ inline void spmm_fold(SpmmArgs const& a, uint32_t col) {
+    __shared__ ColScratch sc;
+    constexpr int WHAT = (EPI == EPI_XPAY_DOT) ? FOLD_DEC34 : (EPI == EPI_AXPY_NRM_DOT) ? FOLD_DECT_FINAL : FOLD_PROBE;
+    fold_tail<R, LN, WHAT>(*a.foldPlan, col, sc);
+}
+
 __device__ inline bool gate_closed(SpmmArgs const& a) {
     if (a.gate == 0) return false;
     if (a.ctl->state != 0) return true;
@@ -244,6 +254,7 @@ __global__ __launch_bounds__(256) void k_spmm_direct(SpmmArgs a) {
             for (int r = 0; r < RANKS; ++r) sum += s[e * RANKS + r];
             write_record<EPI>(a, chunk, LN, e / LN, e % LN, sum);
         }
+        if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
     }
 }
 
@@ -601,6 +612,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at leas
             double const sum = ((s[0][p][j] + s[1][p][j]) + s[2][p][j]) + s[3][p][j];
             write_record<EPI>(a, chunk, LN, p, j, sum);
         }
+        if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
     }
 }
 
@@ -778,6 +790,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
             double const sum = ((s[0][p][j] + s[1][p][j]) + s[2][p][j]) + s[3][p][j];
             write_record<EPI>(a, chunk, LN, p, j, sum);
         }
+        if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
     }
 }
 
@@ -915,6 +928,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
             double const sum = ((s[0][p][j] + s[1][p][j]) + s[2][p][j]) + s[3][p][j];
             write_record<EPI>(a, chunk, LN, p, j, sum);
         }
+        if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
     }
 }
 
@@ -1091,6 +1105,7 @@ __global__ __launch_bounds__(256, (LN <= 32 ? 3 : 2)) void k_spmm_ilvf(SpmmArgs 
             double const sum = ((s[0][p][j] + s[1][p][j]) + s[2][p][j]) + s[3][p][j];
             write_record<EPI>(a, chunk, LN, p, j, sum);
         }
+        if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
     }
 }
 
@@ -1240,6 +1255,7 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8(SpmmArgs a) {
             double const sum = ((s[0][p][jj] + s[1][p][jj]) + s[2][p][jj]) + s[3][p][jj];
             write_record<EPI>(a, chunk, LN, p, jj, sum);
         }
+        if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
     }
 }
 
@@ -1375,6 +1391,7 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
             double const sum = ((s[0][p][j] + s[1][p][j]) + s[2][p][j]) + s[3][p][j];
             write_record<EPI>(a, chunk, LN, p, j, sum);
         }
+        if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
     }
 }
 
@@ -1463,6 +1480,7 @@ __global__ __launch_bounds__(256) void k_spmm_small4(SpmmArgs a) {
                 for (int r = 0; r < LM; ++r) sum += red[p][gg * PG + r * LNS + jx % LNS];
             write_record<EPI>(a, chunk, LN, p, jx, sum);
         }
+        if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
     }
 }
 
@@ -1617,6 +1635,7 @@ static SpmmArgs spmm_args(int epi, DevPlan const& d) {
     a.order = d.order;
     a.ctl = d.ctl; a.v3 = d.v3; a.B = d.R ? d.R : d.B; a.bOfX = d.R ? nullptr : d.bOfX; a.pz = d.pz; a.pd = d.pd;
     a.m3 = d.m3;
+    a.foldPlan = d.fold ? d.self : nullptr;
     a.hashV3 = d.hashV3; a.origCol = d.origCol; a.rowI = d.rowI; a.ilv = d.ilv; a.aOnce = d.aOnce;
     switch (epi) {
     case EPI_XPAY_DOT:     a.X = d.v6; a.Y = d.v9; a.e0 = d.v4; a.e1 = d.v8; a.sc = d.beta; a.gate = 1; a.first = d.first; break;

@@ -16,10 +16,10 @@
 
 #include "tfq_device.hpp"
 #include "tfq_vec.hpp"
+#include "tfq_colops.hpp"
 
 namespace tfq {
 
-#define TFQ_EPS 2.5e-308   // breakdown threshold of the reference, tfqmrgpu_linalg.hxx:31
 
 // ---------------------------------------------------------------------------------------------------
 template <typename R> struct Vec;
@@ -234,6 +234,10 @@ __global__ __launch_bounds__(256) void k_v5_nrm(DevPlan d) {
         if (d.first) sweep(std::true_type{}); else sweep(std::false_type{});
     }
     chunk_reduce<LN, G::VEC, G::T, 1>(acc, s, d.pd + size_t(chunk) * LN, t, d.ilv);
+    if (d.fold) {   // small systems: the last work group of the column runs decT (tau, var, eta, c67) right here
+        __shared__ ColScratch sc;
+        fold_tail<R, LN, FOLD_DECT_C67>(d, col, sc);
+    }
 }
 
 // ---- KD: [x += eta2 v7 (left over from the previous iteration)] ; v7 := v6 + c67a v7 ; x += eta v7 ;
@@ -294,222 +298,39 @@ __global__ __launch_bounds__(256) void k_x_flush(DevPlan d) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Column kernels: one work group per block column.  Sum the chunk records of the column in chunk
-// order (256/LN groups of LN lanes take every G-th record, then the groups are added in order),
-// then run the scalar update for the LN right-hand sides of the column.
-template <int LN, int NPL>
-__device__ inline void column_sum(double const* part, uint32_t c0, uint32_t c1, double* s, double (&res)[NPL]) {
-    constexpr int G = 256 / LN;      // lane groups: group g takes records c0+g, c0+g+G, ...
-    constexpr int U = 8;             // records in flight per lane (independent loads; the order of the sum stays fixed)
-    int const t = threadIdx.x, g = t / LN, j = t % LN;
-    double acc[NPL] = {};
-    if (g < G) {
-        uint32_t c = c0 + g;
-        for (; c + (U - 1) * G < c1; c += U * G) {
-            double v[U][NPL];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int p = 0; p < NPL; ++p) v[u][p] = part[(size_t(c + u * G) * NPL + p) * LN + j];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int p = 0; p < NPL; ++p) acc[p] += v[u][p];
-        }
-        for (; c < c1; c += G)
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) acc[p] += part[(size_t(c) * NPL + p) * LN + j];
-    }
-    __syncthreads();
-    if (g < G)
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) s[(g * NPL + p) * LN + j] = acc[p];
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < NPL; ++p) res[p] = 0;
-    if (t < LN) for (int gg = 0; gg < G; ++gg)
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) res[p] += s[(gg * NPL + p) * LN + t];
-}
-
-// dec35: beta = z/rho, rho = z  (tfqmrgpu_linalg.hxx:50-75)
+// Column kernels: one work group per block column (the operations themselves: tfq_colops.hpp)
 template <typename R, int LN>
 __global__ __launch_bounds__(256) void k_dec35(DevPlan d) {
     if (d.ctl->state != 0) return;
-    __shared__ double s[256 * 2];
-    uint32_t const col = blockIdx.x;
-    double z[2];
-    column_sum<LN, 2>(d.pz, d.colChunkPtr[col], d.colChunkPtr[col + 1], s, z);
-    int const j = threadIdx.x;
-    if (j >= LN) return;
-    size_t const ir = (size_t(col) * 2 + 0) * LN + j, ii = ir + LN;
-    R* rho = (R*)d.rho; R* bet = (R*)d.beta;
-    double const rr = double(rho[ir]), ri = double(rho[ii]);
-    double const abs2rho = rr * rr + ri * ri, abs2z = z[0] * z[0] + z[1] * z[1];
-    d.z[ir] = z[0]; d.z[ii] = z[1];
-    if (abs2z < TFQ_EPS || abs2rho < TFQ_EPS) {
-        d.status[size_t(col) * LN + j] = -1;
-        bet[ir] = 0; bet[ii] = 0; rho[ir] = 0; rho[ii] = 0;
-    } else {
-        double const den = 1. / abs2rho;
-        bet[ir] = R((z[0] * rr + z[1] * ri) * den);
-        bet[ii] = R((z[1] * rr - z[0] * ri) * den);
-        rho[ir] = R(z[0]); rho[ii] = R(z[1]);
-    }
+    __shared__ double s[512];
+    col_dec35<R, LN>(d, blockIdx.x, s);
 }
-
-// dec34: alfa = -rho/z, c67 = z*(var*eta/rho)  (tfqmrgpu_linalg.hxx:116-151)
 template <typename R, int LN>
 __global__ __launch_bounds__(256) void k_dec34(DevPlan d) {
     if (d.ctl->state != 0) return;
-    __shared__ double s[256 * 2];
-    uint32_t const col = blockIdx.x;
-    double z[2];
-    column_sum<LN, 2>(d.pz, d.colChunkPtr[col], d.colChunkPtr[col + 1], s, z);
-    int const j = threadIdx.x;
-    if (j >= LN) return;
-    size_t const ir = (size_t(col) * 2 + 0) * LN + j, ii = ir + LN;
-    // the latest eta is the one of the second half step of the previous iteration (eta2)
-    R const* rho = (R const*)d.rho; R const* eta = (R const*)d.eta2; R* alf = (R*)d.alfa; R* c67 = (R*)d.c67a;
-    double const rr = double(rho[ir]), ri = double(rho[ii]);
-    double const abs2rho = rr * rr + ri * ri, abs2z = z[0] * z[0] + z[1] * z[1];
-    d.z[ir] = z[0]; d.z[ii] = z[1];
-    if (abs2z < TFQ_EPS || abs2rho < TFQ_EPS) {
-        d.status[size_t(col) * LN + j] = -2;
-        alf[ir] = 0; alf[ii] = 0; c67[ir] = 0; c67[ii] = 0;
-    } else {
-        double const er = double(eta[ir]), ei = double(eta[ii]);
-        double const zden = -1. / abs2z;
-        alf[ir] = R((rr * z[0] + ri * z[1]) * zden);
-        alf[ii] = R((ri * z[0] - rr * z[1]) * zden);
-        double const vden = d.var[size_t(col) * LN + j] / abs2rho;
-        double const tr = (er * rr + ei * ri) * vden, ti = (ei * rr - er * ri) * vden;
-        c67[ir] = R(z[0] * tr - z[1] * ti);
-        c67[ii] = R(z[1] * tr + z[0] * ti);
-    }
+    __shared__ double s[512];
+    col_dec34<R, LN>(d, blockIdx.x, s);
 }
-
-// decT: var = d/tau, c = 1/(1+var), tau = d c, eta = -c alfa [, c67 = var c]  (tfqmrgpu_linalg.hxx:195-229)
-// FINAL additionally leaves the per-column record for the stopping test:
-//   colrec[col] = { max_j tau_j/|b_j|^2 , 1 if any RHS of the column is not broken down (-1/-2) }
 template <typename R, int LN, bool SETC67, bool FINAL>
 __global__ __launch_bounds__(256) void k_decT(DevPlan d) {
     if (d.ctl->state != 0) return;
-    __shared__ double s[256];
-    __shared__ double rec[2][LN];
-    uint32_t const col = blockIdx.x;
-    double dd[1];
-    column_sum<LN, 1>(d.pd, d.colChunkPtr[col], d.colChunkPtr[col + 1], s, dd);
-    int const j = threadIdx.x;
-    if (j < LN) {
-        size_t const ir = (size_t(col) * 2 + 0) * LN + j, ii = ir + LN, i1 = size_t(col) * LN + j;
-        R const* alf = (R const*)d.alfa; R* eta = (R*)(FINAL ? d.eta2 : d.eta); R* c67 = (R*)d.c67;
-        double cosi = 0; R r67 = 1;
-        double const Tau = d.tau[i1];
-        int8_t st = d.status[i1];
-        double newTau;
-        if (fabs(Tau) > TFQ_EPS) {
-            double const Var = dd[0] / Tau;
-            cosi = 1. / (1. + Var);
-            d.var[i1] = Var;
-            newTau = dd[0] * cosi;
-            r67 = R(Var * cosi);
-        } else {
-            st = -3; d.status[i1] = -3;
-            d.var[i1] = 0; newTau = 0;
-        }
-        d.tau[i1] = newTau;
-        d.d[i1] = dd[0];
-        if (st < 0) { eta[ir] = 0; eta[ii] = 0; }
-        else { eta[ir] = R(-cosi * alf[ir]); eta[ii] = R(-cosi * alf[ii]); }
-        if (SETC67) { c67[ir] = r67; c67[ii] = 0; }
-        if (FINAL) { rec[0][j] = newTau * d.invBn2[i1]; rec[1][j] = (st == -1 || st == -2) ? 0. : 1.; }
-    }
-    if (FINAL) {
-        __syncthreads();
-        if (0 == j) {
-            double mx = 0, alive = 0; // max ignores NaN like std::max(a, nan) == a in the reference loop
-            for (int jj = 0; jj < LN; ++jj) { if (rec[0][jj] > mx) mx = rec[0][jj]; if (rec[1][jj] > alive) alive = rec[1][jj]; }
-            d.colrec[size_t(col) * 2 + 0] = mx; d.colrec[size_t(col) * 2 + 1] = alive;
-        }
-    }
+    __shared__ double s[512];
+    __shared__ double rec[2][64];
+    col_decT<R, LN, SETC67, FINAL>(d, blockIdx.x, s, rec);
 }
-
-// true residual per RHS of one column after the probe multiply (tfqmrgpu_core.hxx:274-286):
-//   colrec[col] = { max_j res2_j , 1 if any RHS with status 0 has res2 > tol2 }
 template <int LN>
 __global__ __launch_bounds__(256) void k_probe_col(DevPlan d) {
     if (d.ctl->state != 0 || d.ctl->probe == 0) return;
-    __shared__ double s[256];
-    __shared__ double rec[2][LN];
-    uint32_t const col = blockIdx.x;
-    double dd[1];
-    column_sum<LN, 1>(d.pd, d.colChunkPtr[col], d.colChunkPtr[col + 1], s, dd);
-    int const j = threadIdx.x;
-    if (j < LN) {
-        size_t const i1 = size_t(col) * LN + j;
-        double const res2 = dd[0] * d.invBn2[i1];
-        double const tol2 = d.ctl->tol2;
-        double open = 0;
-        if (res2 > tol2) { if (0 == d.status[i1]) open = 1; }
-        else if (res2 <= 0) d.status[i1] = 1;
-        rec[0][j] = res2; rec[1][j] = open;
-    }
-    __syncthreads();
-    if (0 == j) {
-        double mx = 0, open = 0;
-        for (int jj = 0; jj < LN; ++jj) { if (rec[0][jj] > mx) mx = rec[0][jj]; if (rec[1][jj] > open) open = rec[1][jj]; }
-        d.colrec[size_t(col) * 2 + 0] = mx; d.colrec[size_t(col) * 2 + 1] = open;
-    }
+    __shared__ double s[512];
+    __shared__ double rec[2][64];
+    col_probe<LN>(d, blockIdx.x, s, rec);
 }
-
-// ---- single work group: max over the column records, then the stopping decision -------------------
-// what = 0: end of an iteration (tfqmrgpu_core.hxx:239-260), 1: after a probe (:287-298)
-// phase 0: reduce + decide, 1: reduce only into ctl->red (an all-reduce follows), 2: decide only
+// single work group: max over the column records, then the stopping decision
 __global__ __launch_bounds__(256) void k_decide(DevPlan d, int what, int phase) {
-    Ctl* c = d.ctl;
-    if (c->state != 0) return;
-    if (1 == what && 0 == c->probe) return;
+    if (d.ctl->state != 0) return;
+    if (1 == what && 0 == d.ctl->probe) return;
     __shared__ double s0[256], s1[256];
-    int const t = threadIdx.x;
-    if (phase != 2) {
-        double a = 0, b = 0;
-        for (uint32_t col = t; col < d.nCols; col += 256) {
-            double const u = d.colrec[size_t(col) * 2], v = d.colrec[size_t(col) * 2 + 1];
-            if (u > a) a = u; if (v > b) b = v;
-        }
-        s0[t] = a; s1[t] = b;
-        __syncthreads();
-        for (int h = 128; h > 0; h >>= 1) {
-            if (t < h) { if (s0[t + h] > s0[t]) s0[t] = s0[t + h]; if (s1[t + h] > s1[t]) s1[t] = s1[t + h]; }
-            __syncthreads();
-        }
-        if (0 == t) { c->red[3 * what] = s0[0]; c->red[3 * what + 1] = s1[0]; }   // red[3 * what + 2] is the host's: "this rank failed"
-        __syncthreads();
-    }
-    if (phase == 1 || t != 0) return;
-    if (c->red[3 * what + 2] > 0.) { c->state = 4; c->probe = 0; return; }   // some rank failed: every rank stops at this very slot
-    if (0 == what) {
-        int const it = ++c->iteration;
-        double const bound2 = c->red[0] * (2 * it + 1);
-        c->max_bound2 = bound2;
-        int probe = (bound2 <= c->target_bound2) || (it >= c->maxIterations);
-        if (c->red[1] == 0.) { c->state = 2; probe = 0; } // every right-hand side broke down
-        c->probe = probe;
-        c->xpend = 1;   // x += eta2 v7 of this iteration is still outstanding
-    } else {
-        double max_res2 = 1.4e-76;
-        if (c->red[3] > max_res2) max_res2 = c->red[3];
-        c->target_bound2 = (c->max_bound2 / max_res2) * c->tol2;
-        c->nprobes += 1;
-        c->probe = 0;
-        c->xpend = 0;   // k_x_flush has brought x up to date
-        double const before = c->residual2_reached;      // of the previous probe of this solve (1e300 at the start)
-        c->residual2_reached = max_res2;
-        if (c->red[4] == 0.) { c->iterations_needed = c->iteration; c->state = 1; }
-        else if (c->iteration >= c->maxIterations) c->state = 3;
-        else if (c->stallStop && max_res2 > 0.49 * before) c->state = 3;   // |r| no better than 0.7 x the previous probe's: the float floor
-    }
+    decide_body(d, what, phase, s0, s1);
 }
 
 // ---- start of a solve ---------------------------------------------------------------------------
