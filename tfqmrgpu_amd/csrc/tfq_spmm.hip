@@ -36,6 +36,17 @@
 #include "tfq_switch.hpp"
 #include "tfq_colops.hpp"
 
+#ifdef TFQ_LAB
+// lab builds only: shader clock under the real kernel's load.  k_spmm_ilv16 adds, per work group, its lifetime in shader clocks
+// (s_memtime) and in the constant 100 MHz clock (s_memrealtime) to three counters {clocks, ticks, work groups} the caller points to
+// with tfqmrgpuLab_clockRecord (nullptr: off); average frequency = clocks / ticks * 100 MHz (scripts/clock_under_load.py;
+// r03: 2.36-2.38 GHz during a solve -- no throttling under matrix + HBM load, profiles/r03_ab_desc_clock.txt).
+__device__ unsigned long long* g_tfqClockRec = nullptr;
+extern "C" int tfqmrgpuLab_clockRecord(unsigned long long* threeCountersOnTheDevice) {
+    return int(hipMemcpyToSymbol(HIP_SYMBOL(g_tfqClockRec), &threeCountersOnTheDevice, sizeof threeCountersOnTheDevice));
+}
+#endif
+
 namespace tfq {
 
 struct SpmmArgs {
@@ -639,6 +650,9 @@ using f2v = __attribute__((ext_vector_type(2))) float;
 // many columns A is re-used out of the caches and must stay there (the plan decides: SpmmArgs::aOnce).
 template <int EPI, bool HASH, bool ANT = false, bool FIRST = false>   // FIRST: the launch of the first iteration of a solve (SpmmArgs::first)
 __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
+#ifdef TFQ_LAB
+    long long const labC0 = clock64(), labW0 = wall_clock64();
+#endif
     if (gate_closed(a)) return;
     using R = double;
     constexpr int LN = 16, P = 256, NPL = EpiPlanes<EPI>::N;
@@ -792,6 +806,13 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
         }
         if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
     }
+#ifdef TFQ_LAB
+    if (g_tfqClockRec && 0 == threadIdx.x) {
+        atomicAdd(g_tfqClockRec, (unsigned long long)(clock64() - labC0));
+        atomicAdd(g_tfqClockRec + 1, (unsigned long long)(wall_clock64() - labW0));
+        atomicAdd(g_tfqClockRec + 2, 1ull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
