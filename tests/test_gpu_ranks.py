@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("world,name,prec,tol", [(2, "fd_16x16_small", "z", 1e-9), (3, "stencil_8x8", "z", 1e-9),
-                                                 (2, "fd_16x16_2d", "c", 1e-4)])
+                                                 (2, "fd_16x16_2d", "c", 1e-4),
+                                                 (2, "fd_16x16_2d", "m", 1e-9)])     # mixed precision: the refinement's residual rides the same max-reduction
 def test_ranks_sharing_one_gpu(tmp_path, world, name, prec, tol):
     out = str(tmp_path / "sharded.npz")
     env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -364,6 +364,10 @@ __global__ __launch_bounds__(256) void k_init_col(DevPlan d, double tol, int max
         ((R*)d.c67)[ir] = 0; ((R*)d.c67)[ii] = 0; ((R*)d.eta)[ir] = 0; ((R*)d.eta)[ii] = 0;
         ((R*)d.c67a)[ir] = 0; ((R*)d.c67a)[ii] = 0; ((R*)d.eta2)[ir] = 0; ((R*)d.eta2)[ii] = 0;
     }
+    if (0 == t) {   // the arrival counters of the folded column operations start every solve at zero, whatever the previous one left
+        d.foldCount[col] = 0;
+        if (0 == col) d.foldCount[d.nCols] = 0;
+    }
     if (0 == col && 0 == t) {
         Ctl* c = d.ctl;
         double const tol2 = tol * tol;
@@ -443,6 +447,10 @@ __global__ __launch_bounds__(256) void k_refine_init_col(RefineArgs a) {
         double mx = 0, bad = 0;
         for (int j = 0; j < LN; ++j) { if (rec[j] > mx) mx = rec[j]; if (!(rec[j] == rec[j]) || rec[j] > 1e300) bad = 1; }
         d.colrec[size_t(col) * 2 + 0] = mx; d.colrec[size_t(col) * 2 + 1] = bad;
+    }
+    if (0 == t) {
+        d.foldCount[col] = 0;
+        if (0 == col) d.foldCount[d.nCols] = 0;
     }
     if (0 == col && 0 == t) {
         Ctl* c = d.ctl;
