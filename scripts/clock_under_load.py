@@ -4,7 +4,8 @@ work groups of k_spmm_ilv16 = clocks / ticks * 100 MHz, and the average lifetime
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("TFQMRGPU_LIB", os.path.join(ROOT, "tfqmrgpu_amd", "lib", "libtfQMRgpu_lab.so"))
+# needs a build with the clock hook: scripts/build_variant.sh clock -DTFQ_LAB -DTFQ_LAB_CLOCK
+os.environ.setdefault("TFQMRGPU_LIB", os.path.join(ROOT, "scripts", "bin", "libtfQMRgpu_clock.so"))
 import torch
 import tfqmrgpu_amd as T
 from bench import build_problem

@@ -122,7 +122,7 @@ def _user_array(blocks, layout, trans):
 
 
 @pytest.mark.parametrize("prec", ["z", "c"])
-@pytest.mark.parametrize("shape", [(4, 4), (8, 8), (8, 10), (16, 16), (16, 32), (32, 32)])   # 16 x 16, 8 x 8 z / 16 x 16, 32 x 32 c: plans with groups of rows interleaved
+@pytest.mark.parametrize("shape", [(4, 4), (8, 8), (8, 10), (8, 32), (8, 64), (16, 16), (16, 32), (32, 32)])   # 16 x 16, 8 x 8 | 32 | 64 z / 16 x 16, 16 | 32 x 32 c: plans with groups of rows interleaved
 def test_set_get_matrix_layouts(prec, shape):
     LM, LN = shape
     pr = PR.stencil_2d(4, 3, LM, LN, 3, seed=12, radius=1.6)

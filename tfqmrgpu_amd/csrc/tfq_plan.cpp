@@ -246,6 +246,7 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     auto const ilvOf = [&](char prec) {
         int ilv = 0;
         if (ilvEnv && 'z' == prec && ((16 == LM && 16 == LN) || (8 == LM && 8 == LN && ilvEnv != 16))) ilv = 2;
+        if ((1 == ilvEnv || 2 == ilvEnv) && 'z' == prec && 8 == LM && (32 == LN || 64 == LN)) ilv = 2;      // k_spmm_ilv8w (r03)
         if ((1 == ilvEnv || 3 == ilvEnv) && 'c' == prec && 16 == LM && 16 == LN) ilv = 4;
         if (1 == ilvEnv && 'c' == prec && (16 == LM || 32 == LM) && 32 == LN) ilv = 4;   // 16 x 32, 32 x 32 (k_spmm_ilvf)
         return ilv;
@@ -317,6 +318,8 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
 
     size_t at = 0;
     auto take = [&](Window& w, size_t bytes) { w.offset = at; w.bytes = bytes; at = align256(at + bytes); };
+    // (r03: X-shaped vectors that lie exactly 2^k bytes apart -- config 4: 2 GiB, config 5: 512 MiB -- do NOT alias on the memory channels:
+    //  a gap of 4 KiB ... 1 MiB behind each vector changed no kernel time, profiles/r03_ab_ilv8w.txt)
     take(p.wX, p.S);                                  // the solution stays first, as in the reference
     take(p.wV4, p.S); take(p.wV5, p.S); take(p.wV6, p.S);
     take(p.wV7, p.S); take(p.wV8, p.S); take(p.wV9, p.S);

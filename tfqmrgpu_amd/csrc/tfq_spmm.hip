@@ -36,8 +36,9 @@
 #include "tfq_switch.hpp"
 #include "tfq_colops.hpp"
 
-#ifdef TFQ_LAB
-// lab builds only: shader clock under the real kernel's load.  k_spmm_ilv16 adds, per work group, its lifetime in shader clocks
+#ifdef TFQ_LAB_CLOCK
+// builds with -DTFQ_LAB_CLOCK only (scripts/build_variant.sh clock -DTFQ_LAB -DTFQ_LAB_CLOCK; the two clock reads cost k_spmm_ilv16 7 %, so
+// not even the regular lab build carries them): shader clock under the real kernel's load.  k_spmm_ilv16 adds, per work group, its lifetime in shader clocks
 // (s_memtime) and in the constant 100 MHz clock (s_memrealtime) to three counters {clocks, ticks, work groups} the caller points to
 // with tfqmrgpuLab_clockRecord (nullptr: off); average frequency = clocks / ticks * 100 MHz (scripts/clock_under_load.py;
 // r03: 2.36-2.38 GHz during a solve -- no throttling under matrix + HBM load, profiles/r03_ab_desc_clock.txt).
@@ -650,7 +651,7 @@ using f2v = __attribute__((ext_vector_type(2))) float;
 // many columns A is re-used out of the caches and must stay there (the plan decides: SpmmArgs::aOnce).
 template <int EPI, bool HASH, bool ANT = false, bool FIRST = false>   // FIRST: the launch of the first iteration of a solve (SpmmArgs::first)
 __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
-#ifdef TFQ_LAB
+#ifdef TFQ_LAB_CLOCK
     long long const labC0 = clock64(), labW0 = wall_clock64();
 #endif
     if (gate_closed(a)) return;
@@ -806,7 +807,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
         }
         if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
     }
-#ifdef TFQ_LAB
+#ifdef TFQ_LAB_CLOCK
     if (g_tfqClockRec && 0 == threadIdx.x) {
         atomicAdd(g_tfqClockRec, (unsigned long long)(clock64() - labC0));
         atomicAdd(g_tfqClockRec + 1, (unsigned long long)(wall_clock64() - labW0));
@@ -1281,6 +1282,161 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8(SpmmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 8 x 32 and 8 x 64 complex<double> on the row-pair-interleaved order: k_spmm_ilv8's tile ([Re A; Im A] x [Re X | Im X], one exchange
+// with the lane 8 further) once per group of 8 block columns.  A wave-wide 16-byte access covers both planes and all 8 rows of ONE
+// column group (8 segments of 128 bytes), so a block product is 1 + LN / 8 loads of 1 KiB (k_spmm_mfma8 on the native order: 2 + 2 LN / 8
+// of 512 bytes) and every vector of the epilogue LN / 8 accesses per Y block.  No epilogue prefetch (the accumulators of 8 column groups
+// are 64 registers), the shadow vector is read.
+template <int LN, int EPI, bool FIRST = false>   // FIRST: the launch of the first iteration of a solve (SpmmArgs::first)
+__global__ __launch_bounds__(256) void k_spmm_ilv8w(SpmmArgs a) {
+    if (gate_closed(a)) return;
+    using R = double;
+    static_assert(LN % 8 == 0 && LN > 8, "groups of 8 block columns");
+    constexpr int NTB = LN / 8;                       // column groups of a block
+    constexpr int NT = (NTB > 4) ? 4 : NTB;           // column groups of one unit of work of a wave (8 x 64: a Y block is two units;
+                                                      //  all 8 groups in one wave need 255-271 VGPRs = one wave per SIMD)
+    constexpr int HALVES = NTB / NT;
+    constexpr int P = 8 * LN, PA = 64, NPL = EpiPlanes<EPI>::N;
+    constexpr bool UPD = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
+    using T4 = d4;
+    int const lane = threadIdx.x & 63;
+    int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int const lr = lane >> 4, lc = lane & 15, cp = lc >> 3, j = lc & 7;
+    using CU32 = __attribute__((address_space(4))) uint32_t const*;
+    CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
+    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    uint32_t const first = a.chunkFirst[chunk], last = a.chunkFirst[chunk + 1], col = a.chunkCol[chunk];
+    double part[NPL > 0 ? NPL : 1][NT] = {};
+    __shared__ double s[4][NPL > 0 ? NPL : 1][LN];
+    if constexpr (NPL > 0) {   // (8 x 64: a wave meets both halves of the columns only if it has at least two units: clear what it may not write)
+        for (int e = threadIdx.x; e < 4 * NPL * LN; e += 256) (&s[0][0][0])[e] = 0;
+        __syncthreads();
+    }
+
+    R const* const A0 = (R const*)a.A + cp * PA + (lr * 8 + 2 * (j & 3) + (j >> 2)) * 2;   // A: row pi(j) of plane cp, k pair lr (as k_spmm_ilv8)
+    struct Ops { d2v av, xv[NT]; };
+    // units u = wave, wave + 4, ...: unit u is (Y block u / HALVES, half u % HALVES of its column groups); 4 is a multiple of HALVES,
+    // so a wave keeps its half
+    static_assert(4 % HALVES == 0, "a wave keeps its half of the column groups");
+    int const t0 = (wave % HALVES) * NT;                  // first column group of this wave's units
+    // this lane's 16 bytes of column group t0 + t of an X-shaped block: plane cp, row pair lr, column 8 (t0 + t) + j
+    auto mine = [&](int t) { return cp * P + (lr * LN + 8 * (t0 + t) + j) * 2; };
+    auto fetch = [&](Ops& o, uint32_t q) __attribute__((always_inline)) {
+        o.av = *(d2v const*)(A0 + size_t(pairs[2 * size_t(q)]) * 2 * PA);
+        R const* Xb = (R const*)a.X + size_t(pairs[2 * size_t(q) + 1]) * 2 * P;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) o.xv[t] = *(d2v const*)(Xb + mine(t));
+    };
+    for (uint32_t u = wave; u < (last - first) * HALVES; u += 4) {
+        uint32_t const y = first + u / HALVES;
+        T4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = T4{0, 0, 0, 0};
+        uint32_t const q0 = starts[y], q1 = starts[y + 1];
+        auto mma = [&](Ops const& o) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t] = Acc<R>::mma(o.av[0], o.xv[t][0], acc[t]);
+                acc[t] = Acc<R>::mma(o.av[1], o.xv[t][1], acc[t]);
+            }
+        };
+        Ops o0, o1;
+        if (q0 < q1) fetch(o0, q0);
+        if (q0 + 1 < q1) fetch(o1, q0 + 1);
+        uint32_t q = q0;
+        for (; q + 2 <= q1; q += 2) {
+            mma(o0);
+            if (q + 2 < q1) fetch(o0, q + 2);
+            mma(o1);
+            if (q + 3 < q1) fetch(o1, q + 3);
+        }
+        if (q < q1) mma(o0);
+
+        uint32_t bq = 0xffffffffu;
+        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX ? a.bOfX[y] : y;
+        size_t const yb = size_t(y) * 2 * P;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            size_t const yoff = yb + mine(t);
+            // lanes of plane 0 hold (Q00, Q10), lanes of plane 1 (Q01, Q11), rows 2 lr and 2 lr + 1: Re Y = Q00 - Q11, Im Y = Q01 + Q10
+            d2v const qa = d2v{acc[t][0], acc[t][1]}, qb = xor8(d2v{acc[t][2], acc[t][3]});
+            d2v const yM = cp ? d2v{qa[0] + qb[0], qa[1] + qb[1]} : d2v{qa[0] - qb[0], qa[1] - qb[1]};   // this lane's plane of Y
+            d2v const yO = xor8(yM);
+            d2v const yr = cp ? yO : yM, yi = cp ? yM : yO;
+            if constexpr (UPD) {
+                R const srt = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + 8 * (t0 + t) + j];
+                R const sit = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + 8 * (t0 + t) + j];
+                d2v uM = d2v{0, 0}, vM = d2v{0, 0};
+                if constexpr (!(EPI == EPI_XPAY_DOT && FIRST)) {   // (first iteration of a solve: old v4 = v8 = 0, not read)
+                    uM = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff));
+                    if constexpr (EPI == EPI_XPAY_DOT) vM = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff));
+                }
+                f2v const wM = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff));
+                d2v const uO = xor8(uM), ur = cp ? uO : uM, ui = cp ? uM : uO;
+                f2v const wO = f2v{__shfl_xor(wM[0], 8), __shfl_xor(wM[1], 8)};
+                d2v const w0 = cp ? d2v{wO[0], wO[1]} : d2v{wM[0], wM[1]}, w1 = cp ? d2v{wM[0], wM[1]} : d2v{wO[0], wO[1]};
+                d2v nr, ni;
+                if constexpr (EPI == EPI_XPAY_DOT) {          // v9 := A v6; v4 := v8 + beta v4; v4 := v9 + beta v4 (tfqmrgpu_core.hxx:196-202)
+                    d2v const vO = xor8(vM), vr = cp ? vO : vM, vi = cp ? vM : vO;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        R const tr = __builtin_fma(-sit, ui[e], __builtin_fma(srt, ur[e], vr[e]));
+                        R const ti = __builtin_fma(srt, ui[e], __builtin_fma(sit, ur[e], vi[e]));
+                        nr[e] = __builtin_fma(-sit, ti, __builtin_fma(srt, tr, yr[e]));
+                        ni[e] = __builtin_fma(srt, ti, __builtin_fma(sit, tr, yi[e]));
+                    }
+                } else {                                      // v8 := A v6; v5 := alfa v8 + v5 (tfqmrgpu_core.hxx:224-228)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        nr[e] = __builtin_fma(-sit, yi[e], __builtin_fma(srt, yr[e], ur[e]));
+                        ni[e] = __builtin_fma(srt, yi[e], __builtin_fma(sit, yr[e], ui[e]));
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {                 // every lane has both parts: the lanes of plane 0 are the ones that count
+                    double const dr = nr[e], di = ni[e];
+                    part[0][t] = __builtin_fma(-di, w1[e], __builtin_fma(dr, w0[e], part[0][t]));
+                    part[1][t] = __builtin_fma(di, w0[e], __builtin_fma(dr, w1[e], part[1][t]));
+                    if constexpr (EPI == EPI_AXPY_NRM_DOT) part[2][t] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[2][t]));
+                }
+                __builtin_nontemporal_store(yM, (d2v*)((R*)a.Y + yoff));
+                __builtin_nontemporal_store(cp ? ni : nr, (d2v*)((R*)a.e0 + yoff));
+            } else if constexpr (EPI == EPI_RESIDUAL) {       // |A x - b|^2, nothing stored (tfqmrgpu_core.hxx:265-269)
+                d2v bM = d2v{0, 0};
+                if (bq != 0xffffffffu) bM = *(d2v const*)((R const*)a.B + size_t(bq) * 2 * P + mine(t));
+                d2v const bO = xor8(bM), br = cp ? bO : bM, bi = cp ? bM : bO;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    double const dr = yr[e] + R(-1) * br[e], di = yi[e] + R(-1) * bi[e];
+                    part[0][t] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[0][t]));
+                }
+            } else {
+                __builtin_nontemporal_store(yM, (d2v*)((R*)a.Y + yoff));
+            }
+        }
+    }
+    if constexpr (NPL > 0) {
+        // the rows of a column sit 16 lanes apart (lr); lanes 0..7 (plane 0, lr 0) hold the column sums of their column group
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                double v = part[p][t];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (lane < 8) s[wave][p][8 * (t0 + t) + lane] = v;
+            }
+        __syncthreads();
+        for (int e = threadIdx.x; e < NPL * LN; e += 256) {
+            int const p = e / LN, jj = e % LN;
+            double const sum = ((s[0][p][jj] + s[1][p][jj]) + s[2][p][jj]) + s[3][p][jj];
+            write_record<EPI>(a, chunk, LN, p, jj, sum);
+        }
+        if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // MFMA kernel for 8-row blocks (LM == 8, LN % 8 == 0).  A 16x16 tile would be half empty, so the tile is
 // filled with the complex structure instead:   [Re A]             [Re A Re X | Re A Im X]
 //                                               [Im A] (16 x 8)  x  [Re X | Im X] (8 x 16)  =  [Im A Re X | Im A Im X]
@@ -1566,6 +1722,14 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
             }
             if (canHash8 && a.hashV3) k_spmm_ilv8<EPI, canHash8><<<dim3(nWG), dim3(256), 0, s>>>(a);
             else k_spmm_ilv8<EPI, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
+            return;
+        }
+    }
+    if constexpr (LM == 8 && (LN == 32 || LN == 64) && sizeof(R) == 8) {
+        if (a.ilv && a.chunkFirst) {   // row pairs interleaved (tfq_plan.cpp: layoutBuffer)
+            constexpr bool canFirst = (EPI == EPI_XPAY_DOT);
+            if (canFirst && a.first) k_spmm_ilv8w<LN, EPI, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a);
+            else k_spmm_ilv8w<LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
             return;
         }
     }
