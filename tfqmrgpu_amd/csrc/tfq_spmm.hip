@@ -1437,6 +1437,181 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8w(SpmmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 8 x 8, 8 x 32 and 8 x 64 complex<float> with groups of FOUR rows interleaved (plane[r/4][s][r%4], the order of k_spmm_ilv16f): the float
+// counterpart of k_spmm_ilv8 / k_spmm_ilv8w.  The tile is again [Re A; Im A] (16 x 8) x [Re X | Im X] (8 x 16) per group of 8 block columns, but
+// a 16-byte access of a lane is a k QUAD, and a block of 8 rows has only two of them where v_mfma_f32_16x16x4_f32 has four k slots per
+// step: the upper two slots take the NEXT block product of the same Y block (lane groups 0, 1: product q, lane groups 2, 3: product q + 1;
+// both sums land in the same accumulators), so ONE wave-wide 1-KiB access fetches the A blocks of two products, one per column group their X
+// blocks (k_spmm_mfma8<float> on the native order: 4 bytes per lane and access).  Accumulator registers 0..3 of a lane are the rows
+// 4 (lane / 16) .. + 3 of [Re A; Im A] X: lane groups 0, 1 hold the Re A part, groups 2, 3 the Im A part; Re Y = Q00 - Q11 and Im Y = Q01 + Q10
+// meet through one exchange with lane ^ 40 (other lane-group half, other plane), after which lanes 0 .. 31 hold one 16-byte piece of Y each
+// (quad lane / 16 of column lane % 8, plane (lane % 16) / 8) -- the Y block, every epilogue operand and every result of a column group
+// is one half-wave access.  The shadow vector is read.
+template <int LN, int EPI, bool FIRST = false>   // FIRST: the launch of the first iteration of a solve (SpmmArgs::first)
+__global__ __launch_bounds__(256) void k_spmm_ilv8f(SpmmArgs a) {
+    if (gate_closed(a)) return;
+    using R = float;
+    static_assert(LN % 8 == 0, "groups of 8 block columns");
+    constexpr int NTB = LN / 8;                       // column groups of a block
+    constexpr int NT = (NTB > 4) ? 4 : NTB;           // column groups of one unit of work of a wave
+    constexpr int HALVES = NTB / NT;
+    constexpr int P = 8 * LN, PA = 64, NPL = EpiPlanes<EPI>::N;
+    constexpr bool UPD = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
+    int const lane = threadIdx.x & 63;
+    int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int const lr = lane >> 4, lc = lane & 15, cp = lc >> 3, j = lc & 7;
+    int const g = lr & 1;                             // k quad (operands) | row quad (results, lanes 0 .. 31)
+    bool const second = (lr >= 2);                    // operands: this lane feeds the second product of a pair
+    bool const owner = (lr < 2);                      // results: lanes 0 .. 31 own the pieces of Y
+    using CU32 = __attribute__((address_space(4))) uint32_t const*;
+    CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
+    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    uint32_t const first = a.chunkFirst[chunk], last = a.chunkFirst[chunk + 1], col = a.chunkCol[chunk];
+    double part[NPL > 0 ? NPL : 1][NT] = {};
+    __shared__ double s[4][NPL > 0 ? NPL : 1][LN];
+    if constexpr (NPL > 0 && HALVES > 1) {   // a wave writes the sums of its half of the column groups only
+        for (int e = threadIdx.x; e < 4 * NPL * LN; e += 256) (&s[0][0][0])[e] = 0;
+        __syncthreads();
+    }
+    static_assert(4 % HALVES == 0, "a wave keeps its half of the column groups");
+    int const t0 = (wave % HALVES) * NT;              // first column group of this wave's units
+    // 16 bytes of an X-shaped block: plane cp, quad g, column 8 (t0 + t) + j;  of an A block (transposed): plane cp, k quad g, row j
+    auto mine = [&](int t) { return cp * P + (g * LN + 8 * (t0 + t) + j) * 4; };
+    int const mineA = cp * PA + (g * 8 + j) * 4;
+    struct Ops { f4v av, xv[NT]; };
+    auto fetch = [&](Ops& o, uint32_t q, uint32_t q1) __attribute__((always_inline)) {   // products q (lane groups 0, 1) and q + 1 (2, 3)
+        bool const two = (q + 1 < q1);
+        uint32_t const ia0 = pairs[2 * size_t(q)], ix0 = pairs[2 * size_t(q) + 1];
+        uint32_t const ia1 = two ? pairs[2 * size_t(q) + 2] : ia0, ix1 = two ? pairs[2 * size_t(q) + 3] : ix0;
+        uint32_t const ia = second ? ia1 : ia0, ix = second ? ix1 : ix0;
+        o.av = f4v{0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) o.xv[t] = f4v{0, 0, 0, 0};
+        if (!second || two) {
+            o.av = *(f4v const*)((R const*)a.A + size_t(ia) * 2 * PA + mineA);
+            R const* Xb = (R const*)a.X + size_t(ix) * 2 * P;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) o.xv[t] = *(f4v const*)(Xb + mine(t));
+        }
+    };
+    for (uint32_t u = wave; u < (last - first) * HALVES; u += 4) {
+        uint32_t const y = first + u / HALVES;
+        f4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f4{0, 0, 0, 0};
+        uint32_t const q0 = starts[y], q1 = starts[y + 1];
+        auto mma = [&](Ops const& o) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)                   // step e contracts k = 4 g + e of product q (slots 0, 1) and q + 1 (slots 2, 3)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = Acc<R>::mma(o.av[e], o.xv[t][e], acc[t]);
+        };
+        Ops o0, o1;
+        if (q0 < q1) fetch(o0, q0, q1);
+        if (q0 + 2 < q1) fetch(o1, q0 + 2, q1);
+        uint32_t q = q0;
+        for (; q + 4 <= q1 + 1 && q + 2 < q1; q += 4) {   // two pairs per trip while a second pair exists
+            mma(o0);
+            if (q + 4 < q1) fetch(o0, q + 4, q1);
+            mma(o1);
+            if (q + 6 < q1) fetch(o1, q + 6, q1);
+        }
+        if (q < q1) mma(o0);
+
+        uint32_t bq = 0xffffffffu;
+        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX ? a.bOfX[y] : y;
+        size_t const yb = size_t(y) * 2 * P;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            // lane (lr, cp): lr < 2: [Re A X] rows of quad lr, x (Re | Im) X; lr >= 2: [Im A X] rows of quad lr - 2.  Partner lane ^ 40.
+            f4v const v = f4v{acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+            f4v const o = f4v{__shfl_xor(v[0], 40), __shfl_xor(v[1], 40), __shfl_xor(v[2], 40), __shfl_xor(v[3], 40)};
+            // owners: plane 0: Re Y = Q00 - Q11, plane 1: Im Y = Q01 + Q10
+            f4v const yM = cp ? f4v{v[0] + o[0], v[1] + o[1], v[2] + o[2], v[3] + o[3]} : f4v{v[0] - o[0], v[1] - o[1], v[2] - o[2], v[3] - o[3]};
+            f4v const yO = f4v{__shfl_xor(yM[0], 8), __shfl_xor(yM[1], 8), __shfl_xor(yM[2], 8), __shfl_xor(yM[3], 8)};   // the other plane of the same elements
+            f4v const yr = cp ? yO : yM, yi = cp ? yM : yO;
+            size_t const yoff = yb + mine(t);
+            if constexpr (UPD) {
+                R const srt = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + 8 * (t0 + t) + j];
+                R const sit = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + 8 * (t0 + t) + j];
+                f4v uM = f4v{0, 0, 0, 0}, vM = f4v{0, 0, 0, 0}, wM = f4v{0, 0, 0, 0};
+                if (owner) {
+                    if constexpr (!(EPI == EPI_XPAY_DOT && FIRST)) {   // (first iteration of a solve: old v4 = v8 = 0, not read)
+                        uM = __builtin_nontemporal_load((f4v const*)((R const*)a.e0 + yoff));
+                        if constexpr (EPI == EPI_XPAY_DOT) vM = __builtin_nontemporal_load((f4v const*)((R const*)a.e1 + yoff));
+                    }
+                    wM = __builtin_nontemporal_load((f4v const*)(a.v3 + yoff));
+                }
+                auto x8 = [](f4v z) { return f4v{__shfl_xor(z[0], 8), __shfl_xor(z[1], 8), __shfl_xor(z[2], 8), __shfl_xor(z[3], 8)}; };
+                f4v const uO = x8(uM), ur = cp ? uO : uM, ui = cp ? uM : uO;
+                f4v const wO = x8(wM), w0 = cp ? wO : wM, w1 = cp ? wM : wO;
+                f4v nr, ni;
+                if constexpr (EPI == EPI_XPAY_DOT) {          // v9 := A v6; v4 := v8 + beta v4; v4 := v9 + beta v4 (tfqmrgpu_core.hxx:196-202)
+                    f4v const vO = x8(vM), vr = cp ? vO : vM, vi = cp ? vM : vO;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        R const tr = __builtin_fmaf(-sit, ui[e], __builtin_fmaf(srt, ur[e], vr[e]));
+                        R const ti = __builtin_fmaf(srt, ui[e], __builtin_fmaf(sit, ur[e], vi[e]));
+                        nr[e] = __builtin_fmaf(-sit, ti, __builtin_fmaf(srt, tr, yr[e]));
+                        ni[e] = __builtin_fmaf(srt, ti, __builtin_fmaf(sit, tr, yi[e]));
+                    }
+                } else {                                      // v8 := A v6; v5 := alfa v8 + v5 (tfqmrgpu_core.hxx:224-228)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        nr[e] = __builtin_fmaf(-sit, yi[e], __builtin_fmaf(srt, yr[e], ur[e]));
+                        ni[e] = __builtin_fmaf(srt, yi[e], __builtin_fmaf(sit, yr[e], ui[e]));
+                    }
+                }
+                if (owner) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {             // every owner lane has both parts: the lanes of plane 0 are the ones that count
+                        double const dr = nr[e], di = ni[e], x0 = w0[e], x1 = w1[e];
+                        part[0][t] = __builtin_fma(-di, x1, __builtin_fma(dr, x0, part[0][t]));
+                        part[1][t] = __builtin_fma(di, x0, __builtin_fma(dr, x1, part[1][t]));
+                        if constexpr (EPI == EPI_AXPY_NRM_DOT) part[2][t] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[2][t]));
+                    }
+                    __builtin_nontemporal_store(yM, (f4v*)((R*)a.Y + yoff));
+                    __builtin_nontemporal_store(cp ? ni : nr, (f4v*)((R*)a.e0 + yoff));
+                }
+            } else if constexpr (EPI == EPI_RESIDUAL) {       // |A x - b|^2, nothing stored (tfqmrgpu_core.hxx:265-269)
+                f4v bM = f4v{0, 0, 0, 0};
+                if (owner && bq != 0xffffffffu) bM = *(f4v const*)((R const*)a.B + size_t(bq) * 2 * P + mine(t));
+                f4v const bO = f4v{__shfl_xor(bM[0], 8), __shfl_xor(bM[1], 8), __shfl_xor(bM[2], 8), __shfl_xor(bM[3], 8)};
+                f4v const br = cp ? bO : bM, bi = cp ? bM : bO;
+                if (owner) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        R const rr = yr[e] + R(-1) * br[e], ri = yi[e] + R(-1) * bi[e];
+                        double const dr = rr, di = ri;
+                        part[0][t] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[0][t]));
+                    }
+                }
+            } else {
+                if (owner) __builtin_nontemporal_store(yM, (f4v*)((R*)a.Y + yoff));
+            }
+        }
+    }
+    if constexpr (NPL > 0) {
+        // owner lanes of plane 0: lane j of lane group 0 | 1 holds the sums of quad 0 | 1 of column 8 (t0 + t) + j
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                double v = part[p][t];
+                v += __shfl_xor(v, 16);
+                if (lane < 8) s[wave][p][8 * (t0 + t) + lane] = v;
+            }
+        __syncthreads();
+        for (int e = threadIdx.x; e < NPL * LN; e += 256) {
+            int const p = e / LN, jj = e % LN;
+            double const sum = ((s[0][p][jj] + s[1][p][jj]) + s[2][p][jj]) + s[3][p][jj];
+            write_record<EPI>(a, chunk, LN, p, jj, sum);
+        }
+        if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // MFMA kernel for 8-row blocks (LM == 8, LN % 8 == 0).  A 16x16 tile would be half empty, so the tile is
 // filled with the complex structure instead:   [Re A]             [Re A Re X | Re A Im X]
 //                                               [Im A] (16 x 8)  x  [Re X | Im X] (8 x 16)  =  [Im A Re X | Im A Im X]
@@ -1722,6 +1897,14 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
             }
             if (canHash8 && a.hashV3) k_spmm_ilv8<EPI, canHash8><<<dim3(nWG), dim3(256), 0, s>>>(a);
             else k_spmm_ilv8<EPI, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
+            return;
+        }
+    }
+    if constexpr (LM == 8 && (LN == 8 || LN == 32 || LN == 64) && sizeof(R) == 4) {
+        if (4 == a.ilv && a.chunkFirst) {   // quads of rows interleaved (tfq_plan.cpp: layoutBuffer)
+            constexpr bool canFirst = (EPI == EPI_XPAY_DOT);
+            if (canFirst && a.first) k_spmm_ilv8f<LN, EPI, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a);
+            else k_spmm_ilv8f<LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
             return;
         }
     }
