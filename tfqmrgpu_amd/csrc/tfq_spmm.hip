@@ -11,6 +11,7 @@
 // epilogue operand and result of a lane is one 16-byte access), the hot shapes of the BASELINE configurations:
 //  * k_spmm_ilv16  : 16 x 16 complex<double>, row pairs (configs 2 and 4);   k_spmm_ilv8 : 8 x 8 complex<double>, a block = one access (config 5);
 //  * k_spmm_ilv16f : 16 x 16 complex<float>, row quads;                      k_spmm_ilvf : 16 | 32 x 32 complex<float>, row quads (32 x 32: config 3);
+//  * k_spmm_ilv8w  : 8 x 32 | 64 complex<double>, row pairs (r03);            k_spmm_ilv8f : 8 x 8 | 32 | 64 complex<float>, row quads, two products per tile (r03);
 // then, on the reference's native order (every other shape, caller-owned arrays of tfqmrgpuExt_multiply, TFQMRGPU_ILV=0):
 //  * k_spmm_mfma : LM and LN multiples of 16.  One wavefront owns a 16 x LN strip of one Y block
 //    and keeps it in MFMA accumulators (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32).  The
