@@ -389,6 +389,76 @@ __global__ __launch_bounds__(256) void k_init_col(DevPlan d, double tol, int max
 
 // threads t < T handle the elements w = t, t + T, ... of a chunk in the LOGICAL order [block][Re|Im][row][column]; T is a multiple of
 // LN, so a thread keeps its column (right-hand side) j = t % LN
+// the same for plans whose float side keeps quads of rows interleaved (16 x 16, 8 x 8 | 32 | 64, 16 | 32 x 32): an item is one 16-byte piece of R
+// = rows 4 g .. 4 g + 3 of one column; on the double side that is two 16-byte row pairs (ILVZ == 2) or four elements LN apart (native order)
+template <int LM, int LN, int ILVZ>
+__global__ __launch_bounds__(256) void k_refine_residual_q(RefineArgs a) {
+    constexpr int P = LM * LN, T = (256 / LN) * LN, Q = LM / 4, IPB = 2 * Q * LN;   // items per block
+    using f4v = float __attribute__((ext_vector_type(4)));
+    using d2v = double __attribute__((ext_vector_type(2)));
+    __shared__ double s[256];
+    DevPlan const& d = a.d;
+    int const t = threadIdx.x;
+    uint32_t const chunk = blockIdx.x;
+    uint32_t const first = d.chunkFirst[chunk], last = d.chunkFirst[chunk + 1];
+    double acc = 0;
+    float* const R = (float*)d.R;
+    auto quad = [&](double const* base, int g, int q, double (&v)[4]) __attribute__((always_inline)) {
+        if constexpr (ILVZ == 2) {
+            d2v const lo = *(d2v const*)(base + ((2 * g) * LN + q) * 2), hi = *(d2v const*)(base + ((2 * g + 1) * LN + q) * 2);
+            v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = base[(4 * g + i) * LN + q];
+        }
+    };
+    if (t < T) for (uint32_t w = t; w < (last - first) * IPB; w += T) {
+        uint32_t const blk = first + w / IPB;
+        int const e = int(w % IPB), c = e / (Q * LN), g = (e % (Q * LN)) / LN, q = e % LN;
+        uint32_t const bq = d.bOfX[blk];
+        double v[4] = {0, 0, 0, 0}, y[4] = {0, 0, 0, 0};
+        if (0xffffffffu != bq) quad(a.Bz + size_t(bq) * 2 * P + size_t(c) * P, g, q, v);
+        if (a.cycle > 0) quad(a.Yz + size_t(blk) * 2 * P + size_t(c) * P, g, q, y);
+        f4v r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { double const x = v[i] - y[i]; acc = __builtin_fma(x, x, acc); r[i] = float(x); }
+        *(f4v*)(R + size_t(blk) * 2 * P + size_t(c) * P + (g * LN + q) * 4) = r;
+    }
+    s[t] = (t < T) ? acc : 0.;
+    __syncthreads();
+    if (t < LN) {
+        double sum = 0;
+        for (int u = t; u < T; u += LN) sum += s[u];
+        d.pd[size_t(chunk) * LN + t] = sum;
+    }
+}
+
+template <int LM, int LN, int ILVZ>
+__global__ __launch_bounds__(256) void k_refine_update_q(RefineArgs a) {
+    constexpr int P = LM * LN, Q = LM / 4, IPB = 2 * Q * LN;
+    using f4v = float __attribute__((ext_vector_type(4)));
+    using d2v = double __attribute__((ext_vector_type(2)));
+    DevPlan const& d = a.d;
+    uint32_t const chunk = blockIdx.x;
+    uint32_t const first = d.chunkFirst[chunk], last = d.chunkFirst[chunk + 1];
+    float const* const xc = (float const*)d.x;
+    for (uint32_t w = threadIdx.x; w < (last - first) * IPB; w += 256) {
+        uint32_t const blk = first + w / IPB;
+        int const e = int(w % IPB), c = e / (Q * LN), g = (e % (Q * LN)) / LN, q = e % LN;
+        f4v const dx = *(f4v const*)(xc + size_t(blk) * 2 * P + size_t(c) * P + (g * LN + q) * 4);
+        double* const base = a.xz + size_t(blk) * 2 * P + size_t(c) * P;
+        if constexpr (ILVZ == 2) {
+            d2v* const lo = (d2v*)(base + ((2 * g) * LN + q) * 2); d2v* const hi = (d2v*)(base + ((2 * g + 1) * LN + q) * 2);
+            d2v l = d2v{0, 0}, h = d2v{0, 0};
+            if (a.cycle > 0) { l = *lo; h = *hi; }
+            *lo = d2v{l[0] + double(dx[0]), l[1] + double(dx[1])}; *hi = d2v{h[0] + double(dx[2]), h[1] + double(dx[3])};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { double* const z = base + (4 * g + i) * LN + q; *z = (a.cycle > 0) ? *z + double(dx[i]) : double(dx[i]); }
+        }
+    }
+}
+
 template <int LM, int LN>
 __global__ __launch_bounds__(256) void k_refine_residual(RefineArgs a) {
     constexpr int P = LM * LN, T = (256 / LN) * LN;
@@ -541,11 +611,22 @@ hipError_t vec_launch(int op, DevPlan const& d, double tol, int maxIt, hipStream
 template <int LM, int LN>
 static void refine_run(int what, RefineArgs const& a, hipStream_t s) {
     dim3 const grid(a.d.nChunks), cols(a.d.nCols), blk(256);
+    bool const quads = (4 == a.d.ilv) && (0 == a.ilvZ || 2 == a.ilvZ);   // 16-byte pieces on the float side (same arithmetic, same sums)
     if (0 == what) {
-        k_refine_residual<LM, LN><<<grid, blk, 0, s>>>(a);
+        if constexpr (LM % 4 == 0) {
+            if (quads && 2 == a.ilvZ) k_refine_residual_q<LM, LN, 2><<<grid, blk, 0, s>>>(a);
+            else if (quads) k_refine_residual_q<LM, LN, 0><<<grid, blk, 0, s>>>(a);
+            else k_refine_residual<LM, LN><<<grid, blk, 0, s>>>(a);
+        } else k_refine_residual<LM, LN><<<grid, blk, 0, s>>>(a);
         k_refine_init_col<LN><<<cols, blk, 0, s>>>(a);
         k_refine_max<<<1, blk, 0, s>>>(a);
-    } else k_refine_update<LM, LN><<<grid, blk, 0, s>>>(a);
+    } else {
+        if constexpr (LM % 4 == 0) {
+            if (quads && 2 == a.ilvZ) k_refine_update_q<LM, LN, 2><<<grid, blk, 0, s>>>(a);
+            else if (quads) k_refine_update_q<LM, LN, 0><<<grid, blk, 0, s>>>(a);
+            else k_refine_update<LM, LN><<<grid, blk, 0, s>>>(a);
+        } else k_refine_update<LM, LN><<<grid, blk, 0, s>>>(a);
+    }
 }
 static void refine_dispatch(int what, RefineArgs const& a, hipStream_t s) {
     int const key = a.d.LM * 1000 + a.d.LN;
