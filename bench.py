@@ -408,28 +408,30 @@ def main():
 
             # "same A, new B, solve again" (README.md:97-104 of the reference) with B and X resident on the device: setMatrix('B') + solve +
             # getMatrix('X') per right-hand side, the arrays converted in place by the library (no staging, no PCIe)
-            ctype = torch.complex128 if prec == "z" else torch.complex64
-            s.data_precision = prec
-            dB = torch.from_numpy(pr.B).to(ctype).cuda()
-            dXout = torch.empty((pr.nnzbX, pr.LM, pr.LN), dtype=ctype, device="cuda")
-            torch.cuda.synchronize()
-            tr0 = time.perf_counter()
-            for _ in range(args.steps):
-                s.set_matrix_device("B", dB.data_ptr())
-                s.solve(pr.tolerance, args.max_iterations)
-                s.get_matrix_device(dXout.data_ptr())
-            torch.cuda.synchronize()
-            resolve_ms = (time.perf_counter() - tr0) / args.steps * 1e3
-            th0 = time.perf_counter()
-            s.set_matrix("B", pr.B)
-            s.solve(pr.tolerance, args.max_iterations)
-            Xh = s.get_matrix()
-            resolve_host_ms = (time.perf_counter() - th0) * 1e3
-            resolve = dict(resolve_ms=round(resolve_ms, 3), over_solve=round(resolve_ms / (elapsed / args.steps * 1e3), 3),
-                           resolve_host_arrays_ms=round(resolve_host_ms, 1),
-                           note="setMatrix('B') + solve + getMatrix('X'); resolve_ms: B and X in device memory (converted in place by the library), "
-                                "resolve_host_arrays_ms: pageable host arrays (X = %.0f MB over PCIe)" % (S_bytes(pr, prec) / 1e6))
-            del dB, dXout, Xh
+            resolve = None
+            if world == 1:      # (a solve holds the ranks' collectives: never on one rank of several)
+              ctype = torch.complex128 if prec == "z" else torch.complex64
+              s.data_precision = prec
+              dB = torch.from_numpy(pr.B).to(ctype).cuda()
+              dXout = torch.empty((pr.nnzbX, pr.LM, pr.LN), dtype=ctype, device="cuda")
+              torch.cuda.synchronize()
+              tr0 = time.perf_counter()
+              for _ in range(args.steps):
+                  s.set_matrix_device("B", dB.data_ptr())
+                  s.solve(pr.tolerance, args.max_iterations)
+                  s.get_matrix_device(dXout.data_ptr())
+              torch.cuda.synchronize()
+              resolve_ms = (time.perf_counter() - tr0) / args.steps * 1e3
+              th0 = time.perf_counter()
+              s.set_matrix("B", pr.B)
+              s.solve(pr.tolerance, args.max_iterations)
+              Xh = s.get_matrix()
+              resolve_host_ms = (time.perf_counter() - th0) * 1e3
+              resolve = dict(resolve_ms=round(resolve_ms, 3), over_solve=round(resolve_ms / (elapsed / args.steps * 1e3), 3),
+                             resolve_host_arrays_ms=round(resolve_host_ms, 1),
+                             note="setMatrix('B') + solve + getMatrix('X'); resolve_ms: B and X in device memory (converted in place by the library), "
+                                  "resolve_host_arrays_ms: pageable host arrays (X = %.0f MB over PCIe)" % (S_bytes(pr, prec) / 1e6))
+              del dB, dXout, Xh
 
             # the same system in mixed precision (bufferSize 'm': complex<float> tfQMR inside a refinement in double):
             # time to the SAME threshold in double arithmetic, beside the headline figure (which stays the complex<double> solve)
