@@ -50,6 +50,21 @@ def test_tfqmr_mode_matches_the_golden_solve():
 
 
 @pytest.mark.gpu
+def test_tfqmr_mode_in_mixed_precision():
+    # `bench_tfqmrgpu tfQMR file m`: the reference's driver feeds float arrays and passes 'm' on (bench_tfqmrgpu.cu:105,140-153,573);
+    # its library then refuses the solve (status 16, tfqmrgpu.cu:42-44) -- here it converges to the DOUBLE threshold of the file
+    r = subprocess.run([EXE, "tfQMR", os.path.join(GOLD, "fd_16x16_small.xml"), "m", "1", "2000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "requested precision= 'm'" in r.stdout
+    m = re.search(r"# GPU converged to (\S+) in (\d+) iterations", r.stdout)
+    assert m and float(m.group(1)) <= 1e-9 and 14 <= int(m.group(2)) <= 60          # the sum of the float iterations of the refinement
+    py = subprocess.run([os.sys.executable, "-m", "tfqmrgpu_amd.bench_tfqmrgpu", "tfQMR", os.path.join(GOLD, "fd_16x16_small.xml"), "m", "1", "2000"],
+                        capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert py.returncode == 0, py.stdout + py.stderr
+    assert re.search(r"# GPU converged to (\S+) in (\d+) iterations", py.stdout).groups() == m.groups()
+
+
+@pytest.mark.gpu
 def test_tfqmr_mode_extension_lines_and_one_rank_through_rccl():
     # iterations per second and the fused multiply against the HBM roof; `--gpus 1`: a child process per GPU, RCCL communicator
     g = np.load(os.path.join(GOLD, "fd_16x16_2d.npz"))

@@ -93,7 +93,7 @@ def tfqmr(argv):
     from tfqmrgpu_amd import problems as PR
     path = argv[2] if len(argv) > 2 else "problem"
     prec = (argv[3] if len(argv) > 3 else "z")[0].lower()
-    prec = "z" if prec in "dz" else "c"
+    prec = "z" if prec in "dz" else "m" if prec == "m" else "c"   # m: mixed precision, float arrays in and out like the reference's driver
     maxiter = int(argv[5]) if len(argv) > 5 else 2000
     print("\n# read file '%s' as input." % path)
     pr = PR.read_xml(path)
@@ -103,6 +103,8 @@ def tfqmr(argv):
     with T.Solver() as s:
         s.create_plan(pr)
         nbytes = s.buffer_size(pr.LM, pr.LN, prec)
+        if prec == "m":
+            s.data_precision = "c"
         print("# use %.6f GByte GPU memory" % (nbytes * 1e-9))
         s.set_buffer(nbytes=nbytes)
         s.set_matrix("A", pr.A, "n")

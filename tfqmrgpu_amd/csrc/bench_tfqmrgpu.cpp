@@ -465,7 +465,9 @@ int bench_tfqmr(int argc, char** argv) {
     int const n = int(pos.size());
     std::string const path = (n > 2) ? pos[2] : "problem";
     char p0 = (n > 3) ? char(pos[3][0] | 32) : 'z';
-    char const prec = ('d' == p0 || 'z' == p0) ? 'z' : 'c';
+    // z: double, c: float, m: mixed -- float arrays in and out like the reference's driver (bench_tfqmrgpu.cu:140-151,573), solved by
+    // complex<float> iterations inside a refinement in double (the reference's library answers 16 to solve)
+    char const prec = ('d' == p0 || 'z' == p0) ? 'z' : ('m' == p0) ? 'm' : 'c';
     int const maxiter = (n > 5) ? std::atoi(pos[5]) : 2000;
     if (gpus < 1) return tfqmr_rank(path, prec, maxiter, 0, 1, "");
     // one child process per GPU, started before this process has made any HIP call

@@ -478,6 +478,7 @@ static tfqmrgpuStatus_t run_mixed(Handle& h, Plan& p, double tol, int maxIt) {
     // that reaches its floor earlier ends itself (Ctl::stallStop) and the next cycle continues from the double residual
     double const kInnerFloor = 3e-5;
     int used = 0, strikes = 0;
+    bool brokeDown = false;
     double res2 = 1e300, prev2 = 1e300;
     tfqmrgpuStatus_t result = TFQMRGPU_STATUS_MAX_ITERATIONS;
     for (int cycle = 0; ; ++cycle) {
@@ -496,7 +497,10 @@ static tfqmrgpuStatus_t run_mixed(Handle& h, Plan& p, double tol, int maxIt) {
         if (v[1] > 0.) { result = TFQMRGPU_STATUS_BREAKDOWN; break; }      // the residual is not finite
         if (res2 <= tol * tol) { result = TFQMRGPU_STATUS_SUCCESS; break; }
         if (used >= maxIt) break;
-        if (cycle > 0) { strikes = (res2 > 0.25 * prev2) ? strikes + 1 : 0; if (strikes >= 2) break; }   // two cycles in a row gained less than a factor 2
+        if (cycle > 0) {   // two cycles in a row gained less than a factor 2: give up (a breakdown of the last float solve is reported as one)
+            strikes = (res2 > 0.25 * prev2) ? strikes + 1 : 0;
+            if (strikes >= 2) { if (brokeDown) result = TFQMRGPU_STATUS_BREAKDOWN; break; }
+        }
         prev2 = res2;
         double const innerTol = std::min(0.5, std::max(kInnerFloor, 0.25 * tol / std::sqrt(res2)));
         double const t2[2] = { innerTol * innerTol, innerTol * innerTol * 1e4 };   // Ctl::tol2, Ctl::target_bound2 (every rank the same values)
@@ -504,6 +508,7 @@ static tfqmrgpuStatus_t run_mixed(Handle& h, Plan& p, double tol, int maxIt) {
         if (auto const st = run_tfqmr(h, p, d, innerTol, maxIt - used, TFQMRGPU_STATUS_SUCCESS, res2, o)) return st;
         used += o.last.iteration;
         p.cycleIterations.push_back(o.last.iteration);
+        brokeDown = (2 == o.last.state);                                    // every right-hand side of this float solve broke down
         p.flops_performed += fm.solve(o.last) - fm.fNrm;                    // (|r|^2 of the set-up is the refinement's, counted above)
         launch_refine_update(a, s);
         p.flops_performed += 2. * p.nnzbX * p.LM * p.LN;
