@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak run: N solves of one workload on one plan; every solve must give the same iteration count, residual and solution bits
-(the kernels have no atomics and fixed reduction orders).  usage: python scripts/soak.py [workload] [N]"""
+(fixed reduction orders; the arrival counters of the folded column operations decide WHO sums, never in which order).
+usage: python scripts/soak.py [workload] [N] [precision override, e.g. m]"""
 import os, sys, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,6 +11,8 @@ from bench import build_problem
 name = sys.argv[1] if len(sys.argv) > 1 else "fd2d_16x16_z"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 pr, prec, desc = build_problem(name, 0)
+if len(sys.argv) > 3:
+    prec = sys.argv[3]
 s = T.Solver()
 s.create_plan(pr)
 s.set_buffer(nbytes=s.buffer_size(pr.LM, pr.LN, prec))
@@ -25,6 +28,6 @@ for i in range(N):
     seen.setdefault(key, []).append(i)
     if i % 20 == 0:
         print(i, key, sorted(digests), flush=True)
-print("%s: %d solves, distinct (status, iterations, residual): %d, distinct md5 of the sampled solutions: %d" % (name, N, len(seen), len(digests)))
+print("%s (%s): %d solves, distinct (status, iterations, residual): %d, distinct md5 of the sampled solutions: %d" % (name, prec, N, len(seen), len(digests)))
 assert len(seen) == 1, seen
 assert len(digests) == 1, digests
