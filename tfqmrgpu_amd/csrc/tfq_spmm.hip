@@ -264,6 +264,7 @@ __global__ __launch_bounds__(256) void k_spmm_direct(SpmmArgs a) {
         __syncthreads();
         for (int e = t; e < NPL * LN; e += 256) {
             double sum = 0;
+#pragma unroll 1
             for (int r = 0; r < RANKS; ++r) sum += s[e * RANKS + r];
             write_record<EPI>(a, chunk, LN, e / LN, e % LN, sum);
         }
@@ -1829,6 +1830,9 @@ __global__ __launch_bounds__(256) void k_spmm_small4(SpmmArgs a) {
         for (int x = t; x < NPL * LN; x += 256) {
             int const p = x / LN, jx = x % LN;
             double sum = 0;
+            // (not unrolled: with 4 columns and three records the compiler unrolled all 64 terms of a sum and held them in registers --
+            //  134 VGPRs for k_spmm_small4<., 4, EPI_AXPY_NRM_DOT> against 76 for its siblings, half the waves per SIMD; r03)
+#pragma unroll 1
             for (int gg = jx / LNS; gg < NG; gg += NSUB)
                 for (int r = 0; r < LM; ++r) sum += red[p][gg * PG + r * LNS + jx % LNS];
             write_record<EPI>(a, chunk, LN, p, jx, sum);
