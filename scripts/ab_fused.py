@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Same-box A/B of whole library builds on one workload: per-launch time of the two fused multiplies, the plain multiply on the
-plan's data and the iteration, each build in a process of its own (TFQMRGPU_LIB).  usage: python scripts/ab_fused.py <workload> lib1 lib2 ..."""
+plan's data and the iteration, each build in a process of its own (TFQMRGPU_LIB).  usage: python scripts/ab_fused.py <workload> lib1 lib2 ...
+(AB_MAXIT=n caps the iterations: timing-only probe builds give wrong results and would not stop on their own)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -10,22 +11,23 @@ import numpy as np, torch
 import tfqmrgpu_amd as T
 from bench import build_problem
 pr, prec, desc = build_problem(sys.argv[1], 0)
+MAXIT = int(os.environ.get('AB_MAXIT', 2000))
 s = T.Solver()
 s.create_plan(pr)
 s.set_buffer(nbytes=s.buffer_size(pr.LM, pr.LN, prec))
 s.set_matrix("A", pr.A); s.set_matrix("B", pr.B)
-s.solve(pr.tolerance, 2000)
+s.solve(pr.tolerance, MAXIT)
 s.set_profiling(1)
 acc = {}
 for _ in range(3):
-    st = s.solve(pr.tolerance, 2000)
+    st = s.solve(pr.tolerance, MAXIT)
     first = s.profile(first=True)
     for k, (n, ms) in s.profile().items():
         a = acc.setdefault(k, [0, 0.0]); a[0] += n - first[k][0]; a[1] += ms - first[k][1]
 s.set_profiling(0)
 info = s.get_info()
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(5): s.solve(pr.tolerance, 2000)
+for _ in range(5): s.solve(pr.tolerance, MAXIT)
 torch.cuda.synchronize(); solve_ms = (time.perf_counter() - t0) / 5 * 1e3
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.apply_operator(20); torch.cuda.synchronize()

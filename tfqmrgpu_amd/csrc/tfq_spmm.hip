@@ -651,6 +651,13 @@ using f2v = __attribute__((ext_vector_type(2))) float;
 // once per multiply -- the kernel is a stream of A through HBM, and 16-byte non-temporal loads take it from 5.5 to 6.6 TB/s
 // (one block column, 1.3 GB of A: plain multiply 0.69 -> 0.82 of 8 TB/s, fused 0.76 -> 0.85, profiles/r02_lab.txt); with
 // many columns A is re-used out of the caches and must stay there (the plan decides: SpmmArgs::aOnce).
+// TFQ_PROBE (timing-only variants for scripts/build_variant.sh, results WRONG; never set in a build that ships): bit 0: no block products,
+// 1: chunks in linear order, 2: plain instead of non-temporal epilogue accesses, 3: no record reduction, 4: Y not stored, 5: shadow vector = 1
+#ifndef TFQ_PROBE
+#define TFQ_PROBE 0
+#endif
+// ELDS (lab): the epilogue operands (old v4 | v5, v8) land in LDS by LDS-DMA instead of in 16 | 32 VGPRs, which brings the fused
+// instances under 128 VGPRs = four waves per SIMD (4 | 8 KiB of LDS per wave)
 template <int EPI, bool HASH, bool ANT = false, bool FIRST = false>   // FIRST: the launch of the first iteration of a solve (SpmmArgs::first)
 __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
 #ifdef TFQ_LAB_CLOCK
@@ -667,7 +674,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
     // the index lists through the constant address space: uniform reads become scalar loads whatever the stores around them
     using CU32 = __attribute__((address_space(4))) uint32_t const*;
     CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
-    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;   // XCD-aware launch order (tfq_plan.cpp)
+    uint32_t const chunk = (a.order && !(TFQ_PROBE & 2)) ? a.order[blockIdx.x] : blockIdx.x;   // XCD-aware launch order (tfq_plan.cpp)
     uint32_t const first = a.chunkFirst[chunk], last = a.chunkFirst[chunk + 1], col = a.chunkCol[chunk];
     R sr = 0, si = 0;
     if constexpr (UPD) { sr = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + lc]; si = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + lc]; }
@@ -680,11 +687,14 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
     auto fetch = [&](Ops& o, uint32_t q) __attribute__((always_inline)) {
         R const* Ab = A0 + size_t(pairs[2 * size_t(q)]) * 2 * P;
         R const* Xb = X0 + size_t(pairs[2 * size_t(q) + 1]) * 2 * P;
+        bool const ldA = !(TFQ_PROBE & 64) || (q & 6) == 0, ldX = !(TFQ_PROBE & 128) || (q & 6) == 0;   // (probes: 3 of 4 operand fetches skipped, stale registers)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            if (ldA) {
             if constexpr (ANT) { o.ar[h] = __builtin_nontemporal_load((d2v const*)(Ab + h * 128)); o.ai[h] = __builtin_nontemporal_load((d2v const*)(Ab + P + h * 128)); }
             else { o.ar[h] = *(d2v const*)(Ab + h * 128); o.ai[h] = *(d2v const*)(Ab + P + h * 128); }
-            o.xr[h] = *(d2v const*)(Xb + h * 128); o.xi[h] = *(d2v const*)(Xb + P + h * 128);
+            }
+            if (ldX) { o.xr[h] = *(d2v const*)(Xb + h * 128); o.xi[h] = *(d2v const*)(Xb + P + h * 128); }
         }
     };
     for (uint32_t u = wave; u < last - first; u += 4) {
@@ -703,8 +713,11 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
                     cim = Acc<R>::mma(o.ai[h][e], o.xr[h][e], cim);
                 }
         };
-        uint32_t const q0 = starts[y], q1 = starts[y + 1];
+        uint32_t const q0 = starts[y], q1 = (TFQ_PROBE & 1) ? q0 : starts[y + 1];
         Ops o0, o1;
+        if constexpr ((TFQ_PROBE & 192) != 0) {   // (probes: defined contents for the skipped fetches)
+            for (int h = 0; h < 2; ++h) { o0.ar[h] = o0.ai[h] = o0.xr[h] = o0.xi[h] = o1.ar[h] = o1.ai[h] = o1.xr[h] = o1.xi[h] = d2v{1e-3 * lane, 1e-3}; }
+        }
         // the epilogue operands of EPI_AXPY_NRM_DOT (4 loads) are requested in FRONT of the first two block products' operands, those of
         // EPI_XPAY_DOT (8 loads) behind them: measured both ways, profiles/r02_ab_traversal.txt (vmcnt retires in order)
         constexpr bool EPI_FIRST = (EPI == EPI_AXPY_NRM_DOT);
@@ -721,8 +734,8 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
             for (int h = 0; h < 2; ++h) {   // old v4 | v5, v8, v3: touched once, non-temporal
                 if constexpr (EPI == EPI_XPAY_DOT && FIRST) { ur[h] = d2v{0, 0}; ui[h] = d2v{0, 0}; vr[h] = d2v{0, 0}; vi[h] = d2v{0, 0}; }   // first iteration: old v4 = v8 = 0, not read
                 else {
-                ur[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff + eb[h])); ui[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff + eb[h] + P));
-                if constexpr (EPI == EPI_XPAY_DOT) { vr[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff + eb[h])); vi[h] = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff + eb[h] + P)); }
+                ur[h] = ld_stream<!(TFQ_PROBE & 4)>((d2v const*)((R const*)a.e0 + yoff + eb[h])); ui[h] = ld_stream<!(TFQ_PROBE & 4)>((d2v const*)((R const*)a.e0 + yoff + eb[h] + P));
+                if constexpr (EPI == EPI_XPAY_DOT) { vr[h] = ld_stream<!(TFQ_PROBE & 4)>((d2v const*)((R const*)a.e1 + yoff + eb[h])); vi[h] = ld_stream<!(TFQ_PROBE & 4)>((d2v const*)((R const*)a.e1 + yoff + eb[h] + P)); }
                 }
                 if constexpr (!HASH) { wr[h] = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff + eb[h])); wi[h] = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff + eb[h] + P)); }
             }
@@ -749,7 +762,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
         for (int h = 0; h < 2; ++h) {
             // the shadow vector recomputed: one hash for this pair of rows (tfq_device.hpp: shadow_quad).  Drawn here, inside the loop:
             // both hashes in front of it cost spmm_v4_dot 2 % (0.626 against 0.614 ms on P2, profiles/r02_ab_hash.txt)
-            uint64_t const hqh = HASH ? shadow_quad(key, uint32_t(lr + 4 * h), uint32_t(lc), LN) : 0;
+            uint64_t const hqh = (HASH && !(TFQ_PROBE & 32)) ? shadow_quad(key, uint32_t(lr + 4 * h), uint32_t(lc), LN) : 0;
             d2v yr, yi, nr, ni;
             d2v br = d2v{0, 0}, bi = d2v{0, 0};
             if constexpr (EPI == EPI_RESIDUAL) if (bq != 0xffffffffu) {
@@ -784,15 +797,16 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
                     part[0] += dr * dr + di * di;
                 }
             }
-            if constexpr (EPI != EPI_RESIDUAL) {
-                __builtin_nontemporal_store(yr, (d2v*)((R*)a.Y + yoff + eb[h])); __builtin_nontemporal_store(yi, (d2v*)((R*)a.Y + yoff + eb[h] + P));
+            if constexpr (EPI != EPI_RESIDUAL && !((TFQ_PROBE & 16) && UPD)) {
+                st_stream<!(TFQ_PROBE & 4)>((d2v*)((R*)a.Y + yoff + eb[h]), yr); st_stream<!(TFQ_PROBE & 4)>((d2v*)((R*)a.Y + yoff + eb[h] + P), yi);
             }
             if constexpr (UPD) {
-                __builtin_nontemporal_store(nr, (d2v*)((R*)a.e0 + yoff + eb[h])); __builtin_nontemporal_store(ni, (d2v*)((R*)a.e0 + yoff + eb[h] + P));
+                st_stream<!(TFQ_PROBE & 4)>((d2v*)((R*)a.e0 + yoff + eb[h]), nr); st_stream<!(TFQ_PROBE & 4)>((d2v*)((R*)a.e0 + yoff + eb[h] + P), ni);
             }
         }
     }
-    if constexpr (NPL > 0) {
+    if constexpr (NPL > 0 && (TFQ_PROBE & 8)) { if (part[0] == 1.2345e300 && part[1] == 5.4321e300) write_record<EPI>(a, chunk, LN, 0, lane & 15, part[NPL - 1]); }
+    else if constexpr (NPL > 0) {
         // rows live on lane / 16 (and registers): add the four lane groups, then the four waves in order
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
@@ -1864,7 +1878,11 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
                 return;
             }
             if (a.aOnce) { if (hash) k_spmm_ilv16<EPI, canHashI, true><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16<EPI, false, true><<<dim3(nWG), dim3(256), 0, s>>>(a); }
-            else         { if (hash) k_spmm_ilv16<EPI, canHashI, false><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16<EPI, false, false><<<dim3(nWG), dim3(256), 0, s>>>(a); }
+            else {
+                // (lab: unused dynamic LDS per work group limits the work groups per CU -- 60 KiB: two, i.e. two waves per SIMD; the occupancy probe of r03)
+                static size_t const padLds = size_t(lab_switch("TFQMRGPU_ILV16_LDS_KIB", 0)) << 10;
+                if (hash) k_spmm_ilv16<EPI, canHashI, false><<<dim3(nWG), dim3(256), padLds, s>>>(a); else k_spmm_ilv16<EPI, false, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
+            }
             return;
         }
     }
