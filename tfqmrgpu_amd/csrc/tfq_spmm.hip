@@ -72,6 +72,7 @@ struct SpmmArgs {
     int first;                         // EPI_XPAY_DOT in the first iteration of a solve: old v4 = v8 = 0 by definition, not read (DevPlan::first)
     int m3;                            // double shapes above 16 x 16: three real products per complex one (tfqmrgpuExt_setThreeProductMultiply)
     DevPlan const* foldPlan;           // not null: the column operation that consumes this launch's records runs in its tail (tfq_colops.hpp)
+    uint32_t plainPer;                 // plain mode of k_spmm_mfma, not 0: XCD x (work groups x, x + 8, ...) takes the chunks [x * plainPer, (x + 1) * plainPer)
 };
 
 // data that a kernel touches once (epilogue vectors) moves non-temporally, so that the stream does not push the A and
@@ -496,10 +497,10 @@ __global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at leas
     // work groups that are dispatched to the same XCD (blockIdx % 8, observed round-robin) get neighbouring
     // chunks (a.order, tfq_plan.cpp), so that the A blocks shared by neighbouring block columns are served
     // by that XCD's L2
-    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    uint32_t const chunk = a.order ? a.order[blockIdx.x] : a.plainPer ? (blockIdx.x & 7u) * a.plainPer + (blockIdx.x >> 3) : blockIdx.x;
     uint32_t first, last, col = 0;
     if (a.chunkFirst) { first = a.chunkFirst[chunk]; last = a.chunkFirst[chunk + 1]; col = a.chunkCol[chunk]; }
-    else { first = chunk * a.CH; last = min(first + a.CH, a.nY); }
+    else { first = min(chunk * a.CH, a.nY); last = min(first + a.CH, a.nY); }
 
     R sr[NT], si[NT];
 #pragma unroll
@@ -2085,7 +2086,9 @@ tfqmrgpuStatus_t launch_multiply(char precision, int lm, int ln, uint32_t nnzbY,
     if (!mfma) ch = (4 == lm) ? 64 : (lm * ln >= 256) ? 1 : 256 / (lm * ln); // k_spmm_small4: a few sub-blocks per thread group
     if (8 == lm || (4 == lm && dbl && 32 == ln)) ch = (4 == lm) ? 16 : 4;   // k_spmm_mfma8 (kTile8): one Y block per wave and pass
     a.CH = ch;
-    uint32_t const nWG = (nnzbY + ch - 1) / ch;
+    uint32_t nWG = (nnzbY + ch - 1) / ch;
+    // (lab: contiguous eighths of the caller's Y blocks per XCD instead of round-robin work groups)
+    if (mfma && nWG >= 64 && lab_switch("TFQMRGPU_PLAIN_XCD", 0)) { a.plainPer = (nWG + 7) / 8; nWG = 8 * a.plainPer; }
     if (!spmm_dispatch(dbl, lm, ln, EPI_NONE, a, nWG, s))
         return err(TFQMRGPU_BLOCKSIZE_MISSING, ln, lm);
     return (hipSuccess == hipGetLastError()) ? TFQMRGPU_STATUS_SUCCESS : TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
