@@ -124,7 +124,8 @@ SWITCHES = [dict(TFQMRGPU_3M=1), dict(TFQMRGPU_3M=2), dict(TFQMRGPU_EPI_PREFETCH
             dict(TFQMRGPU_DEPTH=1), dict(TFQMRGPU_DEPTH=4), dict(TFQMRGPU_CHUNK_KIB=64), dict(TFQMRGPU_ORDER_G=8),
             dict(TFQMRGPU_ILV=0),     # ILV=0: 16 x 16 and 8 x 8 z plans keep the native element order (k_spmm_mfma / k_spmm_mfma8)
             dict(TFQMRGPU_A_STREAM=0), dict(TFQMRGPU_CLAMP=0),
-            dict(TFQMRGPU_FOLD_MAX=0)]   # the column operations as launches of their own (these small systems fold them into the producers' tails)
+            dict(TFQMRGPU_FOLD_MAX=0),   # the column operations as launches of their own (plans of at most 128 chunks fold them into the producers' tails)
+            dict(TFQMRGPU_FOLD_MAX=100000)]   # ... and folded where the product does not (the first fixture below has 256 chunks)
 
 
 @pytest.mark.parametrize("name,prec,tol", [("stencil:16:16:16:16:4:7:5", "z", 1e-9), ("stencil:8:8:32:32:2:3:13", "z", 1e-9),

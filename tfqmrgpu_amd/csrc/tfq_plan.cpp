@@ -356,9 +356,11 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     take(p.wFold, (size_t(p.nCols) + 1) * sizeof(uint32_t));
     take(p.wSelf, 1024);
     // Small systems fold the column operations into the producers' tails (tfq_colops.hpp): six launches less per iteration slot.
-    // "Small" = the vectors of the whole iteration fit the L2 caches several times over, so the release / acquire of an arrival costs
-    // next to nothing (on P2, 34 522 chunks, it tripled the kernel times: round 1).  Lab builds: TFQMRGPU_FOLD_MAX chunks.
-    p.foldOk = (nChunks <= size_t(lab_switch("TFQMRGPU_FOLD_MAX", 512)));
+    // "Small" = at most 128 chunks, i.e. work groups per multiply: measured with one build and the switch (scripts/fold_crossover.py,
+    // profiles/r03_small_systems.txt) folding gains 14 % at 16 chunks, 3-7 % at 32 ... 128 and LOSES 10-14 % at 256 ... 288 (every
+    // work group pays a device-wide release + an atomic, the last one of a column runs the column's sum alone), 2 x and more from
+    // 1000 chunks on.  Lab builds: TFQMRGPU_FOLD_MAX chunks.
+    p.foldOk = (nChunks <= size_t(lab_switch("TFQMRGPU_FOLD_MAX", 128)));
     take(p.wA, size_t(p.nnzbA) * 2 * LM * LM * p.realBytes);
     if (mixed) {
         // Mixed precision: float vectors for the iteration (above), and in double the solution, B, A (the refinement's residual
