@@ -322,5 +322,10 @@ ak)
   export TFQMRGPU_LIB=$PWD/tfqmrgpu_amd/lib/libtfQMRgpu_lab.so
   for j in 0 1 0 1; do echo "TFQMRGPU_JOIN=$j"; TFQMRGPU_JOIN=$j python scripts/small_latency.py 2>&1 | grep -v amdgpu | tail -3; done
   ;;
+al)
+  # the lab switches added late in the round under test (fold limit 128, forced fold, LDS pad, plain-mode XCD mapping) + the whole GPU suite
+  step 1100 pytest_r03al.log python -m pytest tests -m gpu -q
+  grep -E "^FAILED|passed|failed" gpurun_out/pytest_r03al.log | tail -5
+  ;;
 *) echo "usage: r03.sh <step>; steps:"; grep -E "^[a-z]+\)$" "$0" | tr -d ")" | tr "\n" " "; echo; exit 2 ;;
 esac

@@ -125,7 +125,8 @@ SWITCHES = [dict(TFQMRGPU_3M=1), dict(TFQMRGPU_3M=2), dict(TFQMRGPU_EPI_PREFETCH
             dict(TFQMRGPU_ILV=0),     # ILV=0: 16 x 16 and 8 x 8 z plans keep the native element order (k_spmm_mfma / k_spmm_mfma8)
             dict(TFQMRGPU_A_STREAM=0), dict(TFQMRGPU_CLAMP=0),
             dict(TFQMRGPU_FOLD_MAX=0),   # the column operations as launches of their own (plans of at most 128 chunks fold them into the producers' tails)
-            dict(TFQMRGPU_FOLD_MAX=100000)]   # ... and folded where the product does not (the first fixture below has 256 chunks)
+            dict(TFQMRGPU_FOLD_MAX=100000),
+            dict(TFQMRGPU_ILV16_LDS_KIB=60)]   # the occupancy probe of k_spmm_ilv16: unused dynamic LDS, two work groups per CU   # ... and folded where the product does not (the first fixture below has 256 chunks)
 
 
 @pytest.mark.parametrize("name,prec,tol", [("stencil:16:16:16:16:4:7:5", "z", 1e-9), ("stencil:8:8:32:32:2:3:13", "z", 1e-9),
@@ -143,8 +144,23 @@ def test_tuning_switches_change_code_paths_not_results(tmp_path, name, prec, tol
         assert int(got["status"]) == 0 and int(got["iterations"]) == int(base["iterations"]), sw
         assert np.allclose(got["history"], base["history"], rtol=1e-6, atol=0), sw
         assert np.abs(got["X"] - base["X"]).max() <= 1e-9 * np.abs(base["X"]).max(), sw
-        if "TFQMRGPU_DEPTH" in sw or "TFQMRGPU_ORDER" in sw or "TFQMRGPU_ORDER_G" in sw or "TFQMRGPU_A_STREAM" in sw or "TFQMRGPU_FOLD_MAX" in sw:
+        if "TFQMRGPU_DEPTH" in sw or "TFQMRGPU_ORDER" in sw or "TFQMRGPU_ORDER_G" in sw or "TFQMRGPU_A_STREAM" in sw or "TFQMRGPU_FOLD_MAX" in sw or "TFQMRGPU_ILV16_LDS_KIB" in sw:
             assert np.array_equal(got["X"], base["X"]), sw   # these change WHEN things run, never what is added to what
+
+
+def test_plain_mode_xcd_mapping(tmp_path):
+    """lab switch TFQMRGPU_PLAIN_XCD (native-API multiply: contiguous eighths of the caller's Y blocks per XCD instead of round-robin work
+    groups; profiles/r03_native_multiply.txt): which work group computes a Y block changes, the product does not -- on BASELINE config 1's plan."""
+    got = {}
+    for tag, env in (("product", {}), ("lab", dict(TFQMRGPU_PLAIN_XCD=0)), ("eighths", dict(TFQMRGPU_PLAIN_XCD=1))):
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_multiply_worker.py"), out],
+                           env=dict(os.environ, **{k: str(v) for k, v in env.items()}), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        got[tag] = np.load(out)
+    assert str(got["product"]["lib"]) == "libtfQMRgpu.so" and str(got["eighths"]["lib"]) == "libtfQMRgpu_lab.so"
+    assert np.abs(got["product"]["Y"]).max() > 1
+    assert np.array_equal(got["product"]["Y"], got["lab"]["Y"]) and np.array_equal(got["product"]["Y"], got["eighths"]["Y"])
 
 
 # ---- kernel-level state parity (SURVEY 8 a8-a10: axpy/xpay, dotp/nrm2, dec35/dec34/decT) ----------------------------
