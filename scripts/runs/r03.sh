@@ -327,5 +327,26 @@ al)
   step 1100 pytest_r03al.log python -m pytest tests -m gpu -q
   grep -E "^FAILED|passed|failed" gpurun_out/pytest_r03al.log | tail -5
   ;;
+am)
+  # the 64-column shapes spill (k_spmm_mfma<., ., 64> at 256 VGPRs + 16-176 bytes of scratch): with and without the epilogue-operand prefetch (lab TFQMRGPU_EPI_PREFETCH)
+  L=tfqmrgpu_amd/lib/libtfQMRgpu_lab.so
+  for wl in st:32:64:c:64:64:4 st:64:64:c:45:45:4 st:16:64:c:90:90:4 st:32:64:z:45:45:4 st:64:64:z:32:32:4 st:16:64:z:64:64:4; do
+    for pre in 1 0; do echo "$wl TFQMRGPU_EPI_PREFETCH=$pre"; TFQMRGPU_EPI_PREFETCH=$pre timeout 300 python scripts/ab_fused.py $wl $L 2>&1 | grep -v amdgpu; done
+  done
+  ;;
+an)
+  # 16 | 32 | 64 x 64 complex<float> on the quad-interleaved order, a wave per column half (k_spmm_ilvf, NH = 2): parity, then A/B against k_spmm_mfma (lab TFQMRGPU_ILV64=0)
+  step 900 pytest_r03an.log python -m pytest tests/test_gpu_parity.py tests/test_gpu_hash_mode.py tests/test_gpu_mixed.py -q -x
+  tail -4 gpurun_out/pytest_r03an.log
+  L=tfqmrgpu_amd/lib/libtfQMRgpu_lab.so
+  for wl in st:32:64:c:64:64:4 st:16:64:c:90:90:4 st:64:64:c:45:45:4; do
+    for v in 0 1 0 1; do echo "$wl TFQMRGPU_ILV64=$v"; TFQMRGPU_ILV64=$v timeout 300 python scripts/ab_fused.py $wl $L 2>&1 | grep -v amdgpu; done
+  done
+  ;;
+ao)
+  # after the 64-column float kernel: the whole GPU suite
+  step 1100 pytest_r03ao.log python -m pytest tests -m gpu -q
+  grep -E "^FAILED|passed|failed" gpurun_out/pytest_r03ao.log | tail -5
+  ;;
 *) echo "usage: r03.sh <step>; steps:"; grep -E "^[a-z]+\)$" "$0" | tr -d ")" | tr "\n" " "; echo; exit 2 ;;
 esac

@@ -86,17 +86,24 @@ def test_hash_mode_takes_the_oracles_trajectory_z(oracle, name):
     assert np.abs(X - X0).max() <= 1e-7 * np.abs(X0).max()
 
 
-@pytest.mark.parametrize("name", ["fd_16x16_2d", "fd_16x16_small", "st16x16", "st16x16_ragged", "st16x16_onecol", "st32x32", "stencil_8x8"])
+# 64 columns in complex<float>: k_spmm_ilvf on column halves (r03; two waves of a work group per half, their own record sums)
+C_WIDE = {"st16x64": lambda: PR.stencil_2d(6, 5, 16, 64, 2, seed=5), "st32x64": lambda: PR.stencil_2d(5, 5, 32, 64, 2, seed=6),
+          "st64x64": lambda: PR.stencil_2d(4, 4, 64, 64, 2, seed=8), "st32x64_ragged": lambda: PR.stencil_2d(5, 4, 32, 64, 3, seed=11, radius=2.2)}
+
+
+@pytest.mark.parametrize("name", ["fd_16x16_2d", "fd_16x16_small", "st16x16", "st16x16_ragged", "st16x16_onecol", "st32x32", "stencil_8x8"] + sorted(C_WIDE))
 def test_hash_mode_against_the_oracle_c(oracle, name):
     # complex<float>: both sides round every product to 24 bits in a different order, the trajectories separate after a
     # few iterations: the first two bounds agree to 1e-3, the count to within one iteration, both converge
-    pr = CASES[name]()
+    pr = {**CASES, **C_WIDE}[name]()
     tol = 1e-4
     st, X, info = T.solve_problem(pr, "c", threshold=tol, max_iterations=300)
     st0, X0, info0 = oracle.solve(pr, "c", threshold=tol, max_iterations=300, v3=T.hash_shadow_vector(pr).reshape(-1))
     assert st == st0 == 0
     assert abs(info["iterations"] - info0["iterations"]) <= 1, (info["iterations"], info0["iterations"])
-    assert np.allclose(info["bound_history"][:2], info0["bound_history"][:2], rtol=1e-3, atol=0)
+    # (st64x64 sheds five digits of bound^2 per iteration: its second bound, 1.3e-4 of the first, is already within 1.2e-3 of float rounding)
+    assert np.allclose(info["bound_history"][:2], info0["bound_history"][:2], rtol=3e-3 if "st64x64" == name else 1e-3, atol=0)
+    assert np.allclose(info["bound_history"][:1], info0["bound_history"][:1], rtol=1e-4, atol=0)
     assert info["residual"] <= tol and np.abs(X - X0).max() <= 1e-3 * np.abs(X0).max()
 
 

@@ -122,7 +122,7 @@ def _user_array(blocks, layout, trans):
 
 
 @pytest.mark.parametrize("prec", ["z", "c"])
-@pytest.mark.parametrize("shape", [(4, 4), (8, 8), (8, 10), (8, 32), (8, 64), (16, 16), (16, 32), (32, 32)])   # 16 x 16, 8 x 8 | 32 | 64 z / 16 x 16, 16 | 32 x 32 c: plans with groups of rows interleaved
+@pytest.mark.parametrize("shape", [(4, 4), (8, 8), (8, 10), (8, 32), (8, 64), (16, 16), (16, 32), (32, 32), (16, 64), (32, 64), (64, 64)])   # 16 x 16, 8 x 8 | 32 | 64 z / 16 x 16, 16 | 32 | 64 x 32 | 64 c: plans with groups of rows interleaved
 def test_set_get_matrix_layouts(prec, shape):
     LM, LN = shape
     pr = PR.stencil_2d(4, 3, LM, LN, 3, seed=12, radius=1.6)
@@ -541,7 +541,7 @@ def test_random_ragged_systems(oracle):
 
 
 @pytest.mark.parametrize("prec", ["z", "c"])
-@pytest.mark.parametrize("shape", [(16, 16), (8, 8), (4, 5), (32, 32), (16, 64)])
+@pytest.mark.parametrize("shape", [(16, 16), (8, 8), (4, 5), (32, 32), (16, 64), (32, 64), (64, 64)])
 def test_apply_operator_on_plan_data(oracle, prec, shape):
     """X := A*X with the solver's own multiply kernel and block / element order (16 x 16 z: row pairs interleaved)
     against the oracle's product on the caller's order (reference contract: tfqmrgpu_blockmult.hxx:9-93)"""

@@ -250,6 +250,7 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
         if ((1 == ilvEnv || 3 == ilvEnv) && 'c' == prec && 16 == LM && 16 == LN) ilv = 4;
         if (1 == ilvEnv && 'c' == prec && (16 == LM || 32 == LM) && 32 == LN) ilv = 4;   // 16 x 32, 32 x 32 (k_spmm_ilvf)
         if (1 == ilvEnv && 'c' == prec && 8 == LM && (8 == LN || 32 == LN || 64 == LN)) ilv = 4;   // k_spmm_ilv8f (r03)
+        if (1 == ilvEnv && 'c' == prec && LM >= 16 && 64 == LN && lab_switch("TFQMRGPU_ILV64", 1)) ilv = 4;   // k_spmm_ilvf on column halves (r03)
         return ilv;
     };
     p.ilv = ilvOf(iterPrec);

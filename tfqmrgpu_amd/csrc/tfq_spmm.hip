@@ -973,8 +973,8 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // complex<float> blocks of 16 | 32 rows and 32 columns on the quad-interleaved element order (32 x 32 = BASELINE config 3; written for
-// LM, LN multiples of 16 in general, but with 64 columns it is level with (16 x 64, 32 x 64) or 10 % behind (64 x 64) k_spmm_mfma, where a
-// lane already moves 16 bytes and four tiles of epilogue operands cost a wave per SIMD -- those shapes keep the native order):
+// LM, LN multiples of 16; with 64 columns and all four column tiles in one wave it was level with (16 x 64, 32 x 64) or 10 % behind (64 x 64)
+// k_spmm_mfma in round 2 -- four tiles of accumulators and operands cost a wave per SIMD; since round 3 a wave takes half of the columns, NH below):
 // k_spmm_ilv16f's access pattern with MS x NT MFMA tiles per wave.  A wave owns a strip of MS * 16 rows of a Y block (MS = 2 where the
 // block has two row tiles and 32 columns, else 1: the accumulators stay within 32 VGPRs).  A slice is one group of four k quads (quads
 // lr + 4 m, 16 k values): MS + NT pairs of wave-wide 1-KiB loads feed 16 MS NT MFMAs (32 x 32: 8 loads for 64 MFMAs, against 16 loads of 512
@@ -982,16 +982,21 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
 // The ablations of profiles/r02_ab_config3.txt are why: that kernel gains time with every operand load instruction that is removed.
 // No epilogue-operand prefetch (the registers of the tiles: three waves per SIMD matter more), v3 is read.
 template <int LM, int LN, int EPI, bool FIRST = false>   // FIRST: the launch of the first iteration of a solve (SpmmArgs::first)
-__global__ __launch_bounds__(256, (LN <= 32 ? 3 : 2)) void k_spmm_ilvf(SpmmArgs a) {   // 32 columns: three waves per SIMD (168 VGPRs at most; 64 columns would spill)
+__global__ __launch_bounds__(256, 3) void k_spmm_ilvf(SpmmArgs a) {   // two column tiles per wave: three waves per SIMD (168 VGPRs at most)
     if (gate_closed(a)) return;
     using R = float;
-    constexpr int P = LM * LN, Q = LM * LM, MT = LM / 16, NT = LN / 16, NPL = EpiPlanes<EPI>::N;
+    constexpr int P = LM * LN, Q = LM * LM, MT = LM / 16, NPL = EpiPlanes<EPI>::N;
+    // 64 columns (r03): a wave works on ONE half of the columns (NH = 2 halves of two tiles; the units of a Y block are dealt (strip, half) with the
+    // half running fastest, so wave w of a work group keeps half w % 2 and its per-column scalars and sums) -- all four tiles in one wave need the
+    // registers of two waves per SIMD, and the epilogue stream then does not overlap with the matrix work (32 x 64: 0.526 ms = multiply 0.354 + stream)
+    constexpr int NH = (LN / 16 > 2) ? LN / 32 : 1, NT = LN / 16 / NH;
     constexpr int MS = (MT % 2 == 0 && NT <= 2) ? 2 : 1;          // row tiles per wave
     constexpr int MU = MT / MS;                                   // strips per Y block
     constexpr bool UPD = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
     int const lane = threadIdx.x & 63;
     int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int const lr = lane >> 4, lc = lane & 15;
+    int const c0 = (NH > 1) ? (wave % NH) * 16 * NT : 0;      // first column of this wave's half
     using CU32 = __attribute__((address_space(4))) uint32_t const*;
     CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
     uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;
@@ -1002,8 +1007,8 @@ __global__ __launch_bounds__(256, (LN <= 32 ? 3 : 2)) void k_spmm_ilvf(SpmmArgs 
     if constexpr (UPD) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            sr[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + lc + 16 * nt];
-            si[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + lc + 16 * nt];
+            sr[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + c0 + lc + 16 * nt];
+            si[nt] = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + c0 + lc + 16 * nt];
         }
     }
     double part[NPL > 0 ? NPL : 1][NT] = {};
@@ -1013,10 +1018,10 @@ __global__ __launch_bounds__(256, (LN <= 32 ? 3 : 2)) void k_spmm_ilvf(SpmmArgs 
     auto pieceX = [](int g, int c) { return (g * LN + c) * 4; };
     auto pieceA = [](int g, int c) { return (g * LM + c) * 4; };
     struct Ops { f4v ar[MS], ai[MS], xr[NT], xi[NT]; };
-    uint32_t const nUnits = (last - first) * MU;                  // unit = strip of MS * 16 rows of one Y block
-    for (uint32_t u = wave; u < nUnits; u += 4) {
-        uint32_t const y = first + u / MU;
-        int const t0 = int(u % MU) * MS;                          // first row tile of the strip
+    uint32_t const nUnits = (last - first) * MU * NH;             // unit = strip of MS * 16 rows of one Y block [x half of its columns]
+    for (uint32_t u = wave; u < nUnits; u += 4) {                 // (u % NH == wave % NH: 4 is a multiple of NH)
+        uint32_t const y = first + (u / NH) / MU;
+        int const t0 = int((u / NH) % MU) * MS;                   // first row tile of the strip
         auto fetch = [&](Ops& o, uint32_t q, int m) __attribute__((always_inline)) {
             R const* Ab = (R const*)a.A + size_t(pairs[2 * size_t(q)]) * 2 * Q;
             R const* Xb = (R const*)a.X + size_t(pairs[2 * size_t(q) + 1]) * 2 * P;
@@ -1028,7 +1033,7 @@ __global__ __launch_bounds__(256, (LN <= 32 ? 3 : 2)) void k_spmm_ilvf(SpmmArgs 
                     o.ar[t] = *(f4v const*)(Ab + at); o.ai[t] = *(f4v const*)(Ab + Q + at);
                 }
                 if (t < NT) {
-                    int const at = pieceX(lr + 4 * m, lc + 16 * t);
+                    int const at = pieceX(lr + 4 * m, c0 + lc + 16 * t);
                     o.xr[t] = *(f4v const*)(Xb + at); o.xi[t] = *(f4v const*)(Xb + P + at);
                 }
             }
@@ -1083,7 +1088,7 @@ __global__ __launch_bounds__(256, (LN <= 32 ? 3 : 2)) void k_spmm_ilvf(SpmmArgs 
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 // accumulator registers 0 .. 3 of tile (ms, nt): rows 16 (t0 + ms) + 4 lr .. + 3 of column 16 nt + lc = one 16-byte piece
-                int const at = pieceX(4 * (t0 + ms) + lr, 16 * nt + lc);
+                int const at = pieceX(4 * (t0 + ms) + lr, c0 + 16 * nt + lc);
                 size_t const yoff = size_t(y) * 2 * P + at;
                 f4v ur, ui, vr, vi, wr, wi;
                 if constexpr (UPD) {
@@ -1136,12 +1141,14 @@ __global__ __launch_bounds__(256, (LN <= 32 ? 3 : 2)) void k_spmm_ilvf(SpmmArgs 
                 double v = part[p][nt];
                 v += __shfl_xor(v, 16);
                 v += __shfl_xor(v, 32);
-                if (lane < 16) s[wave][p][lane + 16 * nt] = v;
+                if (lane < 16) s[wave][p][c0 + lane + 16 * nt] = v;
             }
         __syncthreads();
         for (int e = threadIdx.x; e < NPL * LN; e += 256) {
             int const p = e / LN, j = e % LN;
-            double const sum = ((s[0][p][j] + s[1][p][j]) + s[2][p][j]) + s[3][p][j];
+            double sum;
+            if constexpr (NH > 1) sum = s[(j / (16 * NT)) % NH][p][j] + s[(j / (16 * NT)) % NH + 2][p][j];   // the two waves of this column's half
+            else sum = ((s[0][p][j] + s[1][p][j]) + s[2][p][j]) + s[3][p][j];
             write_record<EPI>(a, chunk, LN, p, j, sum);
         }
         if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
@@ -1902,7 +1909,7 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
             return;
         }
     }
-    if constexpr (sizeof(R) == 4 && LM % 16 == 0 && LN == 32) {   // (64 columns: measured level with or behind k_spmm_mfma, whose lanes already move 16 bytes there)
+    if constexpr (sizeof(R) == 4 && LM % 16 == 0 && (LN == 32 || LN == 64)) {
         if (4 == a.ilv && a.chunkFirst) {
             constexpr bool canFirst = (EPI == EPI_XPAY_DOT);
             if (canFirst && a.first) k_spmm_ilvf<LM, LN, EPI, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a);
