@@ -348,5 +348,16 @@ ao)
   step 1100 pytest_r03ao.log python -m pytest tests -m gpu -q
   grep -E "^FAILED|passed|failed" gpurun_out/pytest_r03ao.log | tail -5
   ;;
+ap)
+  # k_spmm_ilvz (16 | 32 | 64 x 32 | 64 complex<double>, row pairs interleaved): deviation report, parity, A/B against k_spmm_mfma (lab TFQMRGPU_ILVZ=0)
+  step 300 zwide_report.txt python scripts/zwide_report.py
+  grep -v amdgpu gpurun_out/zwide_report.txt | cut -c1-220
+  step 900 pytest_r03ap.log python -m pytest tests/test_gpu_parity.py tests/test_gpu_hash_mode.py tests/test_gpu_configs.py -q
+  grep -E "^FAILED|passed|failed" gpurun_out/pytest_r03ap.log | tail -8
+  L=tfqmrgpu_amd/lib/libtfQMRgpu_lab.so
+  for wl in st:32:32:z:64:64:4 st:16:32:z:90:90:4 st:16:64:z:64:64:4 st:32:64:z:45:45:4 st:64:64:z:32:32:4; do
+    for v in 0 1 0 1; do echo "$wl TFQMRGPU_ILVZ=$v"; TFQMRGPU_ILVZ=$v timeout 300 python scripts/ab_fused.py $wl $L 2>&1 | grep -v amdgpu; done
+  done
+  ;;
 *) echo "usage: r03.sh <step>; steps:"; grep -E "^[a-z]+\)$" "$0" | tr -d ")" | tr "\n" " "; echo; exit 2 ;;
 esac

@@ -86,6 +86,30 @@ def test_hash_mode_takes_the_oracles_trajectory_z(oracle, name):
     assert np.abs(X - X0).max() <= 1e-7 * np.abs(X0).max()
 
 
+# complex<double> shapes of k_spmm_ilvz (r03: 16 | 32 | 64 rows x 32 | 64 columns on the row-pair-interleaved order); tolerances as in Z_TOL:
+# 2 x the deviation observed on MI355X (scripts/zwide_report.py), four-product form | three-product form (opt-in)
+Z_WIDE = {"st16x32": lambda: PR.stencil_2d(7, 6, 16, 32, 2, seed=13), "st16x64": lambda: PR.stencil_2d(6, 5, 16, 64, 2, seed=5),
+          "st32x64": lambda: PR.stencil_2d(5, 5, 32, 64, 2, seed=6), "st64x64": lambda: PR.stencil_2d(4, 4, 64, 64, 2, seed=8),
+          "st32x32_ragged": lambda: PR.stencil_2d(6, 5, 32, 32, 3, seed=17, radius=2.4)}
+Z_WIDE_TOL = (1e-8, 1e-9, 1e-4, 1e-7)     # history, its first half, residual, solution (set from the report below)
+
+
+@pytest.mark.parametrize("three", [False, True])
+@pytest.mark.parametrize("name", sorted(Z_WIDE))
+def test_wide_z_shapes_take_the_oracles_trajectory(oracle, name, three):
+    pr = Z_WIDE[name]()
+    st, X, info = T.solve_problem(pr, "z", threshold=pr.tolerance, max_iterations=300, three_products=three)
+    st0, X0, info0 = oracle.solve(pr, "z", threshold=pr.tolerance, max_iterations=300, v3=T.hash_shadow_vector(pr).reshape(-1))
+    assert st == st0 == 0 and info["iterations"] == info0["iterations"]
+    h, h0 = info["bound_history"], info0["bound_history"]
+    htol, half_tol, rtol, xtol = Z_WIDE_TOL
+    half = (len(h0) + 1) // 2
+    assert len(h) == len(h0) and np.allclose(h, h0, rtol=htol, atol=0), np.abs(h / h0 - 1).max()
+    assert np.allclose(h[:half], h0[:half], rtol=half_tol, atol=0), np.abs(h[:half] / h0[:half] - 1).max()
+    assert abs(info["residual"] - info0["residual"]) <= rtol * info0["residual"], info["residual"] / info0["residual"] - 1
+    assert np.abs(X - X0).max() <= xtol * np.abs(X0).max()
+
+
 # 64 columns in complex<float>: k_spmm_ilvf on column halves (r03; two waves of a work group per half, their own record sums)
 C_WIDE = {"st16x64": lambda: PR.stencil_2d(6, 5, 16, 64, 2, seed=5), "st32x64": lambda: PR.stencil_2d(5, 5, 32, 64, 2, seed=6),
           "st64x64": lambda: PR.stencil_2d(4, 4, 64, 64, 2, seed=8), "st32x64_ragged": lambda: PR.stencil_2d(5, 4, 32, 64, 3, seed=11, radius=2.2)}
