@@ -359,5 +359,12 @@ ap)
     for v in 0 1 0 1; do echo "$wl TFQMRGPU_ILVZ=$v"; TFQMRGPU_ILVZ=$v timeout 300 python scripts/ab_fused.py $wl $L 2>&1 | grep -v amdgpu; done
   done
   ;;
+aq)
+  # after taking k_spmm_ilvz out again: the wide-z report on k_spmm_mfma, the whole GPU suite
+  step 300 zwide_report.txt python scripts/zwide_report.py
+  grep -v amdgpu gpurun_out/zwide_report.txt | cut -c1-220
+  step 1100 pytest_r03aq.log python -m pytest tests -m gpu -q
+  grep -E "^FAILED|passed|failed" gpurun_out/pytest_r03aq.log | tail -5
+  ;;
 *) echo "usage: r03.sh <step>; steps:"; grep -E "^[a-z]+\)$" "$0" | tr -d ")" | tr "\n" " "; echo; exit 2 ;;
 esac

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Deviation of the HIP path from the oracle on the z fixtures of the shapes k_spmm_ilvz serves (tests/test_gpu_hash_mode.py: Z_WIDE): iteration
-counts, bound history (whole | first half), residual, solution.  The tolerances of the test are 2 x what this prints on MI355X."""
+"""Deviation of the HIP path from the oracle on the wide complex<double> fixtures (tests/test_gpu_hash_mode.py: Z_WIDE), four- and three-product
+form: iteration counts, bound history (whole | first half), residual, solution.  The tolerances of the test sit above what this prints on MI355X."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1155,173 +1155,9 @@ __global__ __launch_bounds__(256, 3) void k_spmm_ilvf(SpmmArgs a) {   // two col
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// 16 | 32 | 64 x 32 | 64 complex<double> on the row-pair-interleaved element order (r03): k_spmm_ilv16's access pattern -- a lane's 16 bytes are
-// a k pair of its column (X) or of its row (A, stored with r = k), its accumulator registers (0, 1) | (2, 3) the row pairs 2 lr, 2 lr + 8 of a
-// tile -- with one row tile and NT column tiles per wave: a unit of work is (Y block, row tile, group of NT column tiles), dealt with the column
-// group running fastest, so that wave w of a work group keeps group w % (LN / 16 NT), its per-column scalars and its sums (k_spmm_ilvf's halves).
-// k_spmm_mfma holds a whole strip of columns in one wave for these shapes: 210-256 VGPRs (+ scratch with 64 columns) = two waves per SIMD;
-// here (NT = 1) 16 (M3: 24) accumulator and 2 x 32 operand registers: 128-154 VGPRs = three waves, no scratch.  A slice is one k tile of a
-// block product.  M3: the opt-in three-product form (tfqmrgpuExt_setThreeProductMultiply).  v3 is read.
-template <int LM, int LN, int EPI, bool M3, int NT = 1, bool FIRST = false>   // NT: column tiles per wave; FIRST: the launch of the first iteration of a solve (SpmmArgs::first)
-__global__ __launch_bounds__(256, 3) void k_spmm_ilvz(SpmmArgs a) {
-    if (gate_closed(a)) return;
-    using R = double;
-    constexpr int P = LM * LN, Q = LM * LM, MT = LM / 16, NCP = LN / (16 * NT), NPL = EpiPlanes<EPI>::N;
-    static_assert(LM % 16 == 0 && LN % (16 * NT) == 0 && 4 % NCP == 0, "a wave keeps its group of NT column tiles");
-    constexpr bool UPD = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
-    using T4 = d4;
-    int const lane = threadIdx.x & 63;
-    int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int const lr = lane >> 4, lc = lane & 15;
-    int const c0 = (wave % NCP) * 16 * NT;                         // first column of this wave's group of tiles
-    using CU32 = __attribute__((address_space(4))) uint32_t const*;
-    CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
-    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;
-    uint32_t const first = a.chunkFirst[chunk], last = a.chunkFirst[chunk + 1], col = a.chunkCol[chunk];
-    // the sums of this wave live in LDS (its own row of s, no other wave touches it before the barrier at the end) and the per-column scalars
-    // are re-read per unit: with both in registers across the product loop the fused instances spilled 84-270 bytes at the 168 of three waves
-    __shared__ double s[4][NPL > 0 ? NPL : 1][LN];
-    if constexpr (NPL > 0) {
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) if (lane < 16 * NT) s[wave][p][c0 + lane] = 0.;
-    }
-
-    struct Ops { d2v ar[2], ai[2], xr[NT][2], xi[NT][2]; };          // [h]: k pairs lr + 4 h of the k tile
-    int const arow = ilv_rowp(lc);
-    uint32_t const nUnits = (last - first) * MT * NCP;
-    for (uint32_t u = wave; u < nUnits; u += 4) {                 // (u % NCP == wave % NCP: 4 is a multiple of NCP)
-        uint32_t const y = first + (u / NCP) / MT;
-        int const tr = int((u / NCP) % MT);                       // row tile of this unit
-        auto fetch = [&](Ops& o, uint32_t q, int kt) __attribute__((always_inline)) {
-            R const* Ab = (R const*)a.A + size_t(pairs[2 * size_t(q)]) * 2 * Q;
-            R const* Xb = (R const*)a.X + size_t(pairs[2 * size_t(q) + 1]) * 2 * P;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                int const kp = 8 * kt + lr + 4 * h;               // k pair: k = 2 kp, 2 kp + 1
-                int const aa = (kp * LM + 16 * tr + arow) * 2;
-                o.ar[h] = *(d2v const*)(Ab + aa); o.ai[h] = *(d2v const*)(Ab + Q + aa);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    int const xa = (kp * LN + c0 + 16 * nt + lc) * 2;
-                    o.xr[nt][h] = *(d2v const*)(Xb + xa); o.xi[nt][h] = *(d2v const*)(Xb + P + xa);
-                }
-            }
-        };
-        T4 cre[NT], cim[NT], cp3[M3 ? NT : 1];                      // M3: P1 = Re A Re X, P2 = Im A Im X, P3 = (Re A + Im A)(Re X + Im X)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { cre[nt] = T4{0, 0, 0, 0}; cim[nt] = T4{0, 0, 0, 0}; if constexpr (M3) cp3[nt] = T4{0, 0, 0, 0}; }
-        auto mma = [&](Ops const& o) __attribute__((always_inline)) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    R const ar = o.ar[h][e], ai = o.ai[h][e];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        R const xr = o.xr[nt][h][e], xi = o.xi[nt][h][e];
-                        if constexpr (M3) {
-                            cre[nt] = Acc<R>::mma(ar, xr, cre[nt]);
-                            cim[nt] = Acc<R>::mma(ai, xi, cim[nt]);
-                            cp3[nt] = Acc<R>::mma(ar + ai, xr + xi, cp3[nt]);
-                        } else {
-                            cre[nt] = Acc<R>::mma(ar, xr, cre[nt]);
-                            cim[nt] = Acc<R>::mma(ar, xi, cim[nt]);
-                            cre[nt] = Acc<R>::mma(-ai, xi, cre[nt]);
-                            cim[nt] = Acc<R>::mma(ai, xr, cim[nt]);
-                        }
-                    }
-                }
-        };
-        // the slices of the unit in one sequence: slice t = k tile t % MT of block product q0 + t / MT; two register sets
-        uint32_t const q0 = starts[y], q1 = starts[y + 1];
-        uint32_t const nT = (q1 - q0) * MT;
-        Ops o0, o1;
-        if (nT > 0) fetch(o0, q0, 0);
-        if (nT > 1) fetch(o1, q0 + 1 / MT, 1 % MT);              // (MT == 1: slice 1 is the next block product)
-        for (uint32_t t = 0; t < nT; t += 2) {
-            mma(o0);
-            if (t + 2 < nT) fetch(o0, q0 + (t + 2) / MT, int((t + 2) % MT));
-            if (t + 1 < nT) mma(o1);
-            if (t + 3 < nT) fetch(o1, q0 + (t + 3) / MT, int((t + 3) % MT));
-        }
-
-        uint32_t bq = 0xffffffffu;
-        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX ? a.bOfX[y] : y;
-        double part[NPL > 0 ? NPL : 1][NT] = {};
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            R sr = 0, si = 0;
-            if constexpr (UPD) { sr = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + c0 + lc + 16 * nt]; si = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + c0 + lc + 16 * nt]; }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                // accumulator registers (2 h, 2 h + 1) of tile nt: rows 16 tr + 2 (lr + 4 h) + {0, 1} of column c0 + 16 nt + lc = one 16-byte piece
-                int const at = ((8 * tr + lr + 4 * h) * LN + c0 + 16 * nt + lc) * 2;
-                size_t const yoff = size_t(y) * 2 * P + at;
-                d2v ur = d2v{0, 0}, ui = ur, vr = ur, vi = ur; f2v wr = f2v{0, 0}, wi = wr;
-                if constexpr (UPD) {
-                    if constexpr (!(EPI == EPI_XPAY_DOT && FIRST)) {   // (first iteration: old v4 = v8 = 0, not read)
-                        ur = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff)); ui = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff + P));
-                        if constexpr (EPI == EPI_XPAY_DOT) { vr = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff)); vi = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff + P)); }
-                    }
-                    wr = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff)); wi = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff + P));
-                }
-                d2v br = d2v{0, 0}, bi = d2v{0, 0};
-                if constexpr (EPI == EPI_RESIDUAL) if (bq != 0xffffffffu) {
-                    R const* b = (R const*)a.B + size_t(bq) * 2 * P + at;
-                    br = *(d2v const*)b; bi = *(d2v const*)(b + P);
-                }
-                d2v yr, yi, nr, ni;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    if constexpr (M3) { R const p1 = cre[nt][2 * h + e], p2 = cim[nt][2 * h + e]; yr[e] = p1 - p2; yi[e] = (cp3[nt][2 * h + e] - p1) - p2; }
-                    else { yr[e] = cre[nt][2 * h + e]; yi[e] = cim[nt][2 * h + e]; }
-                    if constexpr (EPI == EPI_XPAY_DOT) {         // v9 := A v6; v4 := v8 + beta v4; v4 := v9 + beta v4 (tfqmrgpu_core.hxx:196-202)
-                        R const tr_ = __builtin_fma(-si, ui[e], __builtin_fma(sr, ur[e], vr[e]));
-                        R const ti_ = __builtin_fma(sr, ui[e], __builtin_fma(si, ur[e], vi[e]));
-                        nr[e] = __builtin_fma(-si, ti_, __builtin_fma(sr, tr_, yr[e]));
-                        ni[e] = __builtin_fma(sr, ti_, __builtin_fma(si, tr_, yi[e]));
-                    } else if constexpr (EPI == EPI_AXPY_NRM_DOT) { // v8 := A v6; v5 := alfa v8 + v5 (tfqmrgpu_core.hxx:224-228)
-                        nr[e] = __builtin_fma(-si, yi[e], __builtin_fma(sr, yr[e], ur[e]));
-                        ni[e] = __builtin_fma(sr, yi[e], __builtin_fma(si, yr[e], ui[e]));
-                    }
-                    if constexpr (UPD) {
-                        double const w0 = wr[e], w1 = wi[e], dr = nr[e], di = ni[e];
-                        part[0][nt] = __builtin_fma(-di, w1, __builtin_fma(dr, w0, part[0][nt]));
-                        part[1][nt] = __builtin_fma(di, w0, __builtin_fma(dr, w1, part[1][nt]));
-                        if constexpr (EPI == EPI_AXPY_NRM_DOT) part[2][nt] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[2][nt]));
-                    } else if constexpr (EPI == EPI_RESIDUAL) {     // |A x - b|^2, nothing stored (tfqmrgpu_core.hxx:265-269)
-                        R const rr = yr[e] + R(-1) * br[e], ri = yi[e] + R(-1) * bi[e];
-                        part[0][nt] = __builtin_fma(ri, ri, __builtin_fma(rr, rr, part[0][nt]));
-                    }
-                }
-                if constexpr (EPI != EPI_RESIDUAL) { __builtin_nontemporal_store(yr, (d2v*)((R*)a.Y + yoff)); __builtin_nontemporal_store(yi, (d2v*)((R*)a.Y + yoff + P)); }
-                if constexpr (UPD) { __builtin_nontemporal_store(nr, (d2v*)((R*)a.e0 + yoff)); __builtin_nontemporal_store(ni, (d2v*)((R*)a.e0 + yoff + P)); }
-            }
-        }
-        if constexpr (NPL > 0) {   // rows live on lane / 16 (and registers): add the four lane groups, then onto this wave's sums
-#pragma unroll
-            for (int p = 0; p < NPL; ++p)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    double v = part[p][nt];
-                    v += __shfl_xor(v, 16);
-                    v += __shfl_xor(v, 32);
-                    if (lane < 16) s[wave][p][c0 + lane + 16 * nt] += v;
-                }
-        }
-    }
-    if constexpr (NPL > 0) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < NPL * LN; e += 256) {
-            int const p = e / LN, j = e % LN;
-            double sum = 0;                                     // the waves of this column group, in order
-            for (int w = (j / (16 * NT)) % NCP; w < 4; w += NCP) sum += s[w][p][j];
-            write_record<EPI>(a, chunk, LN, p, j, sum);
-        }
-        if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
-    }
-}
+// (r03: k_spmm_ilvz, the wide complex<double> shapes on the row-pair-interleaved order with one column tile per wave and three waves per SIMD, was
+//  4-22 % slower than k_spmm_mfma below -- twice the operand loads per MFMA; two tiles per wave spill at 168 VGPRs -- and is in the git history only:
+//  commit 167d902, profiles/r03_ab_ilvz.txt)
 
 // ---------------------------------------------------------------------------------------------------
 // 8 x 8 complex<double> on the row-pair-interleaved element order (BASELINE config 5: the bandwidth-bound shape).
@@ -2096,23 +1932,6 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
             }
             if (canHash8 && a.hashV3) k_spmm_ilv8<EPI, canHash8><<<dim3(nWG), dim3(256), 0, s>>>(a);
             else k_spmm_ilv8<EPI, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
-            return;
-        }
-    }
-    if constexpr (sizeof(R) == 8 && LM % 16 == 0 && (LN == 32 || LN == 64)) {
-        if (2 == a.ilv && a.chunkFirst) {   // row pairs interleaved (tfq_plan.cpp: layoutBuffer)
-            constexpr bool canFirst = (EPI == EPI_XPAY_DOT);
-#ifndef TFQ_ILVZ_NT
-#define TFQ_ILVZ_NT 1
-#endif
-            constexpr int NTW = TFQ_ILVZ_NT;   // column tiles per wave (variant builds: 2 -- fewer loads per MFMA, but hipcc spills 36-330 bytes at the 168 VGPRs of three waves)
-            if (a.m3) {
-                if (canFirst && a.first) k_spmm_ilvz<LM, LN, EPI, true, NTW, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a);
-                else k_spmm_ilvz<LM, LN, EPI, true, NTW><<<dim3(nWG), dim3(256), 0, s>>>(a);
-            } else {
-                if (canFirst && a.first) k_spmm_ilvz<LM, LN, EPI, false, NTW, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a);
-                else k_spmm_ilvz<LM, LN, EPI, false, NTW><<<dim3(nWG), dim3(256), 0, s>>>(a);
-            }
             return;
         }
     }
