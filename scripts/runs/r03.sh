@@ -366,5 +366,19 @@ aq)
   step 1100 pytest_r03aq.log python -m pytest tests -m gpu -q
   grep -E "^FAILED|passed|failed" gpurun_out/pytest_r03aq.log | tail -5
   ;;
+ar)
+  # mixed precision: the digits still missing split evenly over cycles of at most 3 digits (TFQMRGPU_MIXED_SPLIT=1) against a quarter of what is missing per cycle (=0)
+  export TFQMRGPU_LIB=$PWD/tfqmrgpu_amd/lib/libtfQMRgpu_lab.so
+  for wl in fd2d_16x16_z stencil2d_8x8_z st:32:32:z:48:48:4 st:16:16:z:96:96:8 fd2d_16x16_z_small; do
+    for v in 0 1 2; do echo "TFQMRGPU_MIXED_SPLIT=$v"; TFQMRGPU_MIXED_SPLIT=$v timeout 300 python scripts/mixed_trace.py $wl 2>&1 | grep -v amdgpu; done
+  done
+  TFQMRGPU_MIXED_SPLIT=0 timeout 300 python scripts/mixed_trace.py fd2d_16x16_z 1e-6 2>&1 | grep -v amdgpu
+  TFQMRGPU_MIXED_SPLIT=1 timeout 300 python scripts/mixed_trace.py fd2d_16x16_z 1e-6 2>&1 | grep -v amdgpu
+  TFQMRGPU_MIXED_SPLIT=1 timeout 300 python scripts/mixed_trace.py fd2d_16x16_z 1e-12 2>&1 | grep -v amdgpu
+  TFQMRGPU_MIXED_SPLIT=0 timeout 300 python scripts/mixed_trace.py fd2d_16x16_z 1e-12 2>&1 | grep -v amdgpu
+  unset TFQMRGPU_LIB
+  step 600 pytest_r03ar.log python -m pytest tests/test_gpu_mixed.py tests/test_gpu_ranks.py -q
+  tail -3 gpurun_out/pytest_r03ar.log
+  ;;
 *) echo "usage: r03.sh <step>; steps:"; grep -E "^[a-z]+\)$" "$0" | tr -d ")" | tr "\n" " "; echo; exit 2 ;;
 esac

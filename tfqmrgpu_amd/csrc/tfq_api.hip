@@ -479,7 +479,7 @@ static tfqmrgpuStatus_t run_mixed(Handle& h, Plan& p, double tol, int maxIt) {
     double const kInnerFloor = 3e-5;
     int used = 0, strikes = 0;
     bool brokeDown = false;
-    double res2 = 1e300, prev2 = 1e300;
+    double res2 = 1e300, prev2 = 1e300, bestGain = 1.;
     tfqmrgpuStatus_t result = TFQMRGPU_STATUS_MAX_ITERATIONS;
     for (int cycle = 0; ; ++cycle) {
         if (cycle > 0) { spmm_apply(dz, dz.x, (void*)a.Yz, s); p.flops_performed += fm.fMult; }
@@ -497,12 +497,30 @@ static tfqmrgpuStatus_t run_mixed(Handle& h, Plan& p, double tol, int maxIt) {
         if (v[1] > 0.) { result = TFQMRGPU_STATUS_BREAKDOWN; break; }      // the residual is not finite
         if (res2 <= tol * tol) { result = TFQMRGPU_STATUS_SUCCESS; break; }
         if (used >= maxIt) break;
+        if (cycle > 0 && prev2 > 0. && prev2 < 1e299) bestGain = std::min(bestGain, std::sqrt(res2 / prev2));   // what the last cycle delivered
         if (cycle > 0) {   // two cycles in a row gained less than a factor 2: give up (a breakdown of the last float solve is reported as one)
             strikes = (res2 > 0.25 * prev2) ? strikes + 1 : 0;
             if (strikes >= 2) { if (brokeDown) result = TFQMRGPU_STATUS_BREAKDOWN; break; }
         }
         prev2 = res2;
-        double const innerTol = std::min(0.5, std::max(kInnerFloor, 0.25 * tol / std::sqrt(res2)));
+        // What this cycle is asked for.  The first cycle: a quarter of what is missing -- the floor of a float solve is not known beforehand (2.4e-4 on
+        // P2, 2.4e-7 on a 32 x 32 stencil); a solve that reaches it ends itself (Ctl::stallStop) at the price of 2-3 iterations.  Later cycles know
+        // what a cycle has delivered (bestGain): if what is missing is more than that, it is split evenly over the cycles it will take anyway, so
+        // that none of them runs into its floor (P2: 9 + 9 + 5 -> 9 + 6 + 5 float iterations); systems whose first cycle delivers nearly everything keep
+        // their two cycles.  Lab builds: TFQMRGPU_MIXED_SPLIT=0 a quarter of what is missing in every cycle, =2 an even split into cycles of at
+        // most 3 digits from the first cycle on (P2: 7 + 7 + 5, but fast-converging systems then take three cycles: profiles/r03_mixed_policy.txt).
+        static int const splitEnv = lab_switch("TFQMRGPU_MIXED_SPLIT", 1);
+        double const need = tol / std::sqrt(res2);                                   // the factor still to gain, < 1
+        double ask = 0.25 * need;
+        if (2 == splitEnv) {
+            int const n = std::max(1, int(std::ceil(-std::log10(need) / 3.0)));
+            if (n > 1) ask = std::pow(need, 1. / n); else ask = 0.5 * need;
+        } else if (1 == splitEnv && cycle > 0 && bestGain < 1.) {
+            double const cap = std::min(0.5, 2. * bestGain);                         // what a cycle delivers without searching for its floor
+            int const n = std::max(1, int(std::ceil(std::log(need) / std::log(cap))));
+            if (n > 1) ask = std::pow(need, 1. / n);
+        }
+        double const innerTol = std::min(0.5, std::max(kInnerFloor, ask));
         double const t2[2] = { innerTol * innerTol, innerTol * innerTol * 1e4 };   // Ctl::tol2, Ctl::target_bound2 (every rank the same values)
         TFQ_HIP(hipMemcpyAsync(&d.ctl->tol2, t2, sizeof t2, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
         if (auto const st = run_tfqmr(h, p, d, innerTol, maxIt - used, TFQMRGPU_STATUS_SUCCESS, res2, o)) return st;

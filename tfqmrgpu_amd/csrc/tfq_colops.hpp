@@ -212,10 +212,14 @@ __device__ inline void decide_body(DevPlan const& d, int what, int phase, double
         c->probe = 0;
         c->xpend = 0;   // k_x_flush has brought x up to date
         double const before = c->residual2_reached;      // of the previous probe of this solve (1e300 at the start)
+        double const promised = (c->probe_bound2 > 0.) ? c->max_bound2 / c->probe_bound2 : 0.;   // what the bound has gained since then (squared)
         c->residual2_reached = max_res2;
+        c->probe_bound2 = c->max_bound2;
         if (c->red[4] == 0.) { c->iterations_needed = c->iteration; c->state = 1; }
         else if (c->iteration >= c->maxIterations) c->state = 3;
-        else if (c->stallStop && max_res2 > 0.49 * before) c->state = 3;   // |r| no better than 0.7 x the previous probe's: the float floor
+        // the float floor (inner solves of 'm'): |r| no better than 0.7 x the previous probe's, or -- seen one probe earlier -- |r| improved 3 x less
+        // than the recurrence's bound did while gaining less than a digit: the recurrence has come loose from the true residual
+        else if (c->stallStop && (max_res2 > 0.49 * before || (promised > 0. && max_res2 > 9. * promised * before && max_res2 > 0.01 * before))) c->state = 3;
     }
 }
 

@@ -19,6 +19,7 @@ struct Ctl {
     double residual2_reached;  // max_rhs |A x - b|^2/|b|^2 at the latest probe
     double red[6];             // max-reduced over ranks: {max tau/|b|^2, any RHS alive, a rank failed} per iteration,
                                //                          {max res^2, any RHS unconverged, a rank failed} per probe
+    double probe_bound2;       // max_bound2 at the latest probe (0: no probe yet): what the recurrence promised since then, for the stall test
     int32_t iteration;         // completed iterations
     int32_t maxIterations;
     int32_t state;             // 0 running, 1 converged, 2 all RHS broke down, 3 out of iterations, 4 stopped: a rank reported a failure
@@ -27,9 +28,10 @@ struct Ctl {
     int32_t nprobes;
     int32_t xpend;             // x += eta2*v7 of the last iteration has not been applied yet
     int32_t stallStop;         // inner solves of the mixed-precision mode: a probe that finds the true residual no better than 0.7 x the
-                               // previous probe's ends the solve (state 3): the float iteration has reached its floor
+                               // previous probe's -- or improved by 3 x less than the recurrence's bound since then -- ends the solve
+                               // (state 3): the float iteration has reached its floor
 };
-static_assert(sizeof(Ctl) == 112, "Ctl is copied as a whole");
+static_assert(sizeof(Ctl) == 120, "Ctl is copied as a whole");
 
 // device pointers of one plan (all inside the user's work buffer)
 struct DevPlan {

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void k_init_col(DevPlan d, double tol, int max
     if (0 == col && 0 == t) {
         Ctl* c = d.ctl;
         double const tol2 = tol * tol;
-        c->tol2 = tol2; c->target_bound2 = tol2 * 100 * 100; c->max_bound2 = 0; c->residual2_reached = 1e300;
+        c->tol2 = tol2; c->target_bound2 = tol2 * 100 * 100; c->max_bound2 = 0; c->residual2_reached = 1e300; c->probe_bound2 = 0;
         for (int i = 0; i < 6; ++i) c->red[i] = 0;
         c->iteration = 0; c->maxIterations = maxIterations;
         c->state = (maxIterations > 0) ? 0 : 3;
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void k_refine_init_col(RefineArgs a) {
     if (0 == col && 0 == t) {
         Ctl* c = d.ctl;
         double const tol2 = a.innerTol * a.innerTol;
-        c->tol2 = tol2; c->target_bound2 = tol2 * 100 * 100; c->max_bound2 = 0; c->residual2_reached = 1e300;
+        c->tol2 = tol2; c->target_bound2 = tol2 * 100 * 100; c->max_bound2 = 0; c->residual2_reached = 1e300; c->probe_bound2 = 0;
         for (int i = 0; i < 6; ++i) c->red[i] = 0;
         c->iteration = 0; c->maxIterations = a.innerMaxIt;
         c->state = (a.innerMaxIt > 0) ? 0 : 3;
