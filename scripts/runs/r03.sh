@@ -380,5 +380,10 @@ ar)
   step 600 pytest_r03ar.log python -m pytest tests/test_gpu_mixed.py tests/test_gpu_ranks.py -q
   tail -3 gpurun_out/pytest_r03ar.log
   ;;
+at)
+  # config 5 (8 x 8 z): timing-only probes of k_spmm_ilv8 -- 3 of 4 A fetches skipped (64), X fetches (128), both (192): is the L2 -> L1 operand path what bounds it?
+  export AB_MAXIT=30
+  timeout 800 python scripts/ab_fused.py stencil2d_8x8_z tfqmrgpu_amd/lib/libtfQMRgpu.so scripts/bin/libtfQMRgpu_p64.so scripts/bin/libtfQMRgpu_p128.so scripts/bin/libtfQMRgpu_p192.so tfqmrgpu_amd/lib/libtfQMRgpu.so 2>&1 | grep -v amdgpu
+  ;;
 *) echo "usage: r03.sh <step>; steps:"; grep -E "^[a-z]+\)$" "$0" | tr -d ")" | tr "\n" " "; echo; exit 2 ;;
 esac

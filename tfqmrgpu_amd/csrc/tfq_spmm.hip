@@ -1196,8 +1196,8 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8(SpmmArgs a) {
     R const* const X0 = (R const*)a.X + mine;
     struct Ops { d2v av, xv; };
     auto fetch = [&](Ops& o, uint32_t q) __attribute__((always_inline)) {
-        o.av = *(d2v const*)(A0 + size_t(pairs[2 * size_t(q)]) * 2 * P);
-        o.xv = *(d2v const*)(X0 + size_t(pairs[2 * size_t(q) + 1]) * 2 * P);
+        if (!(TFQ_PROBE & 64) || (q & 3) == 0) o.av = *(d2v const*)(A0 + size_t(pairs[2 * size_t(q)]) * 2 * P);       // (probes: 3 of 4 fetches skipped, stale registers)
+        if (!(TFQ_PROBE & 128) || (q & 3) == 0) o.xv = *(d2v const*)(X0 + size_t(pairs[2 * size_t(q) + 1]) * 2 * P);
     };
     for (uint32_t u = wave; u < last - first; u += 4) {
         uint32_t const y = first + u;
@@ -1206,6 +1206,7 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8(SpmmArgs a) {
         uint32_t const q0 = starts[y], nq = starts[y + 1] - q0;
         constexpr int DEPTH = 4;
         Ops o[DEPTH];
+        if constexpr ((TFQ_PROBE & 192) != 0) { for (int dd = 0; dd < DEPTH; ++dd) { o[dd].av = d2v{1e-3 * lane, 1e-3}; o[dd].xv = o[dd].av; } }   // (probes: defined contents)
         constexpr bool EPI_FIRST = true;   // epilogue operands requested in front of the first products' operands: -1 % (profiles/r02_ab_traversal.txt)
         if constexpr (!EPI_FIRST) {
 #pragma unroll
