@@ -385,5 +385,21 @@ at)
   export AB_MAXIT=30
   timeout 800 python scripts/ab_fused.py stencil2d_8x8_z tfqmrgpu_amd/lib/libtfQMRgpu.so scripts/bin/libtfQMRgpu_p64.so scripts/bin/libtfQMRgpu_p128.so scripts/bin/libtfQMRgpu_p192.so tfqmrgpu_amd/lib/libtfQMRgpu.so 2>&1 | grep -v amdgpu
   ;;
+au)
+  # column batches (k_spmm_ilv8b: 8 x 8 z block columns with identical row patterns multiplied two at a time): parity, then A/B on config 5 (lab TFQMRGPU_BATCH=1: off)
+  step 900 pytest_r03au.log python -m pytest tests/test_gpu_parity.py tests/test_gpu_hash_mode.py tests/test_gpu_configs.py tests/test_gpu_mixed.py tests/test_gpu_ranks.py -q -x
+  tail -3 gpurun_out/pytest_r03au.log
+  L=tfqmrgpu_amd/lib/libtfQMRgpu_lab.so
+  for wl in stencil2d_8x8_z st:8:8:z:512:512:8 st:8:8:z:256:256:4; do
+    for v in 1 2 1 2; do echo "$wl TFQMRGPU_BATCH=$v"; TFQMRGPU_BATCH=$v timeout 300 python scripts/ab_fused.py $wl $L 2>&1 | grep -v amdgpu; done
+  done
+  ;;
+av)
+  # column batches, epilogue operands requested in front of the products again: A/B on config 5 (lab TFQMRGPU_BATCH=1: off)
+  L=tfqmrgpu_amd/lib/libtfQMRgpu_lab.so
+  for wl in stencil2d_8x8_z st:8:8:z:512:512:8 st:8:8:z:256:256:4; do
+    for v in 1 2 1 2; do echo "$wl TFQMRGPU_BATCH=$v"; TFQMRGPU_BATCH=$v timeout 300 python scripts/ab_fused.py $wl $L 2>&1 | grep -v amdgpu; done
+  done
+  ;;
 *) echo "usage: r03.sh <step>; steps:"; grep -E "^[a-z]+\)$" "$0" | tr -d ")" | tr "\n" " "; echo; exit 2 ;;
 esac

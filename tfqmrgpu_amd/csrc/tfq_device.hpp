@@ -55,6 +55,8 @@ struct DevPlan {
     double *pz, *pd;                           // [nChunks][2|1][LN]
     double* colrec;                            // [nCols][2]
     uint32_t const *chunkFirst, *chunkCol, *colChunkPtr, *colStart, *bOfX, *order;
+    uint32_t const* orderB; uint32_t nChunksB;  // launch order and size of the batched multiply: the chunks of the batches' first columns
+    uint8_t const* colBatch;                   // not null: (batch size << 4) | position per block column -- columns with identical row patterns, multiplied together (k_spmm_ilv8b)
     uint32_t const *starts, *pairs, *subset, *bColPtr, *bList, *u2i, *rowI;
     int32_t const* origCol;
     void const* R;                             // not null: the right-hand side of THIS solve is the X-shaped vector R (the residual of the

@@ -256,6 +256,25 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     p.ilv = ilvOf(iterPrec);
     p.ilvZ = mixed ? ilvOf('z') : 0;
 
+    // Column batches (k_spmm_ilv8b, 8 x 8 complex<double>): runs of up to kColBatchMax neighbouring block columns whose row patterns are identical -- same
+    // block rows in the same order, hence the same chunk cuts and the same A blocks per row -- are multiplied together, one A fetch for the block products of all of them.  Dense right-hand-side columns (BASELINE config 5) qualify; columns truncated around different centres do not.  Lab: TFQMRGPU_BATCH=1 off.
+    p.colBatch.clear();
+    if ('z' == iterPrec && 8 == LM && 8 == LN && 2 == p.ilv) {
+        int const maxB = std::min(kColBatchMax, std::max(1, lab_switch("TFQMRGPU_BATCH", kColBatchMax)));
+        p.colBatch.assign(p.nCols, uint8_t(1 << 4));
+        bool any = false;
+        for (uint32_t c = 0; c < p.nCols; ) {
+            uint32_t const n0 = p.colStart[c + 1] - p.colStart[c];
+            uint32_t nb = 1;
+            while (int(nb) < maxB && c + nb < p.nCols && p.colStart[c + nb + 1] - p.colStart[c + nb] == n0 && n0 > 0 &&
+                   std::equal(p.rowI.begin() + p.colStart[c], p.rowI.begin() + p.colStart[c + 1], p.rowI.begin() + p.colStart[c + nb])) ++nb;
+            for (uint32_t k = 0; k < nb; ++k) p.colBatch[c + k] = uint8_t((nb << 4) | k);
+            any = any || nb > 1;
+            c += nb;
+        }
+        if (!any) p.colBatch.clear();
+    }
+
     // chunks: runs of CH blocks inside one column, sized so that a chunk of one vector is 8..16 KiB and the
     // grid has a few thousand work groups when the problem is large enough
     {
@@ -315,8 +334,24 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
                 for (uint32_t x = 0; x < 8; ++x)
                     if (begin[x] + i < begin[x + 1]) c.order[w++] = sorted[begin[x] + i];
         }
+        c.orderB.clear();
+        if (!p.colBatch.empty()) {   // the same order over the chunks of the batches' first columns only: every work group of that launch has work
+            std::vector<uint32_t> lead;
+            for (uint32_t ch : sorted) if (0 == (p.colBatch[c.col[ch]] & 15)) lead.push_back(ch);
+            uint32_t const nl = uint32_t(lead.size()), q = nl / 8, r = nl % 8;
+            c.orderB = lead;
+            if (mode && n >= 64) {
+                std::vector<uint32_t> begin(9, 0);
+                for (uint32_t x = 0; x < 8; ++x) begin[x + 1] = begin[x] + q + (x < r ? 1 : 0);
+                uint32_t w = 0;
+                for (uint32_t i = 0; i <= q; ++i)
+                    for (uint32_t x = 0; x < 8; ++x)
+                        if (begin[x] + i < begin[x + 1]) c.orderB[w++] = lead[begin[x] + i];
+            }
+        }
     }
     size_t const nChunks = p.chunks.col.size();
+    if (nChunks <= 128) { p.colBatch.clear(); p.chunks.orderB.clear(); }   // small plans fold their column operations into the multiplies' tails instead (below)
 
     size_t at = 0;
     auto take = [&](Window& w, size_t bytes) { w.offset = at; w.bytes = bytes; at = align256(at + bytes); };
@@ -346,6 +381,8 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     take(p.wColChunkPtr, (size_t(p.nCols) + 1) * sizeof(uint32_t));
     take(p.wColStart, (size_t(p.nCols) + 1) * sizeof(uint32_t));
     take(p.wOrigCol, size_t(p.nCols) * sizeof(int32_t));
+    take(p.wColBatch, size_t(p.nCols));
+    take(p.wOrderB, p.chunks.orderB.size() * sizeof(uint32_t));
     take(p.wBofX, size_t(p.nnzbX) * sizeof(uint32_t));         // B block on each X block or ~0
     take(p.wStarts, p.starts_i.size() * sizeof(uint32_t));
     take(p.wPairs, p.pairs_i.size() * sizeof(uint32_t));

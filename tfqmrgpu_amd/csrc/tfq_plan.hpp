@@ -27,6 +27,7 @@ struct ChunkTable {
     std::vector<uint32_t> col;     // [nChunks]   compressed block column
     std::vector<uint32_t> colPtr;  // [nCols+1]   first chunk of each column
     std::vector<uint32_t> order;   // [nChunks]   launch order of the multiply (XCD aware)
+    std::vector<uint32_t> orderB;  // column batches (Plan::colBatch): the chunks of the batches' first columns, in the same kind of order
 };
 
 struct Handle {
@@ -84,6 +85,7 @@ struct Plan {
     Window wPz, wPd;                           // per-chunk partial sums (double)
     Window wColRec;                            // per-column stopping-test record [nCols][2] double
     Window wChunkFirst, wChunkCol, wColChunkPtr, wColStart, wOrigCol, wBofX, wOrder;
+    Window wColBatch, wOrderB; std::vector<uint8_t> colBatch;   // batches of block columns with identical row patterns (empty: none); layoutBuffer
     Window wStarts, wPairs, wSubset, wBColPtr, wBList, wU2I, wRowI;
     // 'm' only: the solution, B and A in double; the residual of the refinement as the right-hand side of the inner (float) solve,
     // |b|^2 per right-hand side, the record of the refinement's stopping test

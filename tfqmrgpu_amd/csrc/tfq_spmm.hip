@@ -72,6 +72,7 @@ struct SpmmArgs {
     int first;                         // EPI_XPAY_DOT in the first iteration of a solve: old v4 = v8 = 0 by definition, not read (DevPlan::first)
     int m3;                            // double shapes above 16 x 16: three real products per complex one (tfqmrgpuExt_setThreeProductMultiply)
     DevPlan const* foldPlan;           // not null: the column operation that consumes this launch's records runs in its tail (tfq_colops.hpp)
+    uint8_t const* colBatch; uint32_t const* colStart; uint32_t const* colChunkPtr;   // k_spmm_ilv8b: (batch size << 4) | position per block column; block / chunk ranges of the columns
     uint32_t plainPer;                 // plain mode of k_spmm_mfma, not 0: XCD x (work groups x, x + 8, ...) takes the chunks [x * plainPer, (x + 1) * plainPer)
 };
 
@@ -1311,6 +1312,170 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8(SpmmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 8 x 8 complex<double>, COLUMN-BATCHED (r03).  Block columns whose row patterns are identical (Plan::colBatch: dense right-hand-side columns, BASELINE
+// config 5) are multiplied nb <= 4 at a time: the work group of chunk c of the FIRST column of a batch also does chunk c of the other columns -- same
+// block rows, same A blocks, the X / Y blocks a column's block count further on -- so that an A block is fetched once for nb block products; the launch
+// runs over the chunks of the batches' first columns only (DevPlan::orderB).  With blocks of 1 KiB the operand path bounds this shape (timing-only probe, profiles/r03_probes.txt:
+// 3 of 4 A fetches skipped = -16 % / -22 % on the fused multiplies).  Chunks, records and every sum are those of k_spmm_ilv8: bit-identical results.
+template <int EPI, bool HASH, int NB, bool FIRST = false>   // NB: columns of a batch at most; FIRST: the launch of the first iteration of a solve (SpmmArgs::first)
+__global__ __launch_bounds__(256, 3) void k_spmm_ilv8b(SpmmArgs a) {
+    if (gate_closed(a)) return;
+    using R = double;
+    constexpr int LN = 8, P = 64, NPL = EpiPlanes<EPI>::N;
+    constexpr bool UPD = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
+    using T4 = d4;
+    int const lane = threadIdx.x & 63;
+    int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int const lr = lane >> 4, lc = lane & 15, cp = lc >> 3, j = lc & 7;
+    using CU32 = __attribute__((address_space(4))) uint32_t const*;
+    CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
+    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    uint32_t const first = a.chunkFirst[chunk], last = a.chunkFirst[chunk + 1], col = a.chunkCol[chunk];
+    uint32_t const cb = a.colBatch[col];
+    if (cb & 15u) return;                       // (a later column of a batch: not in this launch's order, SpmmArgs::order = DevPlan::orderB)
+    int const nb = int(cb >> 4);                // 1 ... NB columns
+    uint32_t dBlk[NB], dChk[NB];                // how far the blocks / chunks of column col + k lie behind those of column col
+    R sr[NB], si[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        dBlk[k] = 0; dChk[k] = 0; sr[k] = 0; si[k] = 0;
+        if (k < nb) {
+            dBlk[k] = a.colStart[col + k] - a.colStart[col]; dChk[k] = a.colChunkPtr[col + k] - a.colChunkPtr[col];
+            if constexpr (UPD) { sr[k] = ((R const*)a.sc)[(size_t(col + k) * 2 + 0) * LN + j]; si[k] = ((R const*)a.sc)[(size_t(col + k) * 2 + 1) * LN + j]; }
+        }
+    }
+    double part[NB][NPL > 0 ? NPL : 1] = {};
+    __shared__ double s[NB][4][NPL > 0 ? NPL : 1][LN];
+
+    int const mine = cp * P + (lr * 8 + j) * 2;                                 // this lane's 16 bytes of an X-shaped block
+    R const* const A0 = (R const*)a.A + cp * P + (lr * 8 + 2 * (j & 3) + (j >> 2)) * 2;   // A: row pi(j) of plane cp, k pair lr
+    R const* const X0 = (R const*)a.X + mine;
+    struct Ops { d2v av; d2v xv[NB]; };
+    auto fetch = [&](Ops& o, uint32_t q) __attribute__((always_inline)) {
+        o.av = *(d2v const*)(A0 + size_t(pairs[2 * size_t(q)]) * 2 * P);
+        uint32_t const xb = pairs[2 * size_t(q) + 1];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) if (k < nb) o.xv[k] = *(d2v const*)(X0 + size_t(xb + dBlk[k]) * 2 * P);
+    };
+    for (uint32_t u = wave; u < last - first; u += 4) {
+        uint32_t const y = first + u;
+        T4 acc[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) acc[k] = T4{0, 0, 0, 0};
+        uint32_t const q0 = starts[y], nq = starts[y + 1] - q0;
+        constexpr int DEPTH = 2;
+        Ops o[DEPTH];
+#pragma unroll
+        for (int dd = 0; dd < DEPTH; ++dd) if (uint32_t(dd) < nq) fetch(o[dd], q0 + dd);
+        for (uint32_t base = 0; base < nq; base += DEPTH) {
+#pragma unroll
+            for (int dd = 0; dd < DEPTH; ++dd) {
+                if (base + dd < nq) {
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) if (k < nb) {
+                        acc[k] = Acc<R>::mma(o[dd].av[0], o[dd].xv[k][0], acc[k]);
+                        acc[k] = Acc<R>::mma(o[dd].av[1], o[dd].xv[k][1], acc[k]);
+                    }
+                    if (base + dd + DEPTH < nq) fetch(o[dd], q0 + base + dd + DEPTH);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) if (k < nb) {
+            size_t const yoff = size_t(y + dBlk[k]) * 2 * P + mine;
+            d2v uMk = d2v{0, 0}, vMk = d2v{0, 0}; f2v wMk = f2v{0, 0};
+            if constexpr (UPD) {   // (requested here, not in front of the products: measured better with two columns per wave)
+                if constexpr (!(EPI == EPI_XPAY_DOT && FIRST)) {   // (first iteration of a solve: old v4 = v8 = 0, not read)
+                    uMk = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff));
+                    if constexpr (EPI == EPI_XPAY_DOT) vMk = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff));
+                }
+                if constexpr (!HASH) wMk = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff));
+            }
+            // lanes of plane 0 hold (Q00, Q10), lanes of plane 1 (Q01, Q11), rows 2 lr and 2 lr + 1: Re Y = Q00 - Q11, Im Y = Q01 + Q10
+            d2v const qa = d2v{acc[k][0], acc[k][1]}, qb = xor8(d2v{acc[k][2], acc[k][3]});
+            d2v const yM = cp ? d2v{qa[0] + qb[0], qa[1] + qb[1]} : d2v{qa[0] - qb[0], qa[1] - qb[1]};   // this lane's plane of Y
+            d2v const yO = xor8(yM);
+            d2v const yr = cp ? yO : yM, yi = cp ? yM : yO;
+            if constexpr (UPD) {
+                d2v const uO = xor8(uMk), ur = cp ? uO : uMk, ui = cp ? uMk : uO;
+                d2v nr, ni;
+                d2v w0, w1;     // the shadow vector: Re and Im of the two elements
+                if constexpr (HASH) {
+                    uint64_t const key = shadow_key(uint32_t(a.origCol[col + k]), a.rowI[y]);   // (the batch's columns have the same block rows)
+                    uint64_t const hq = shadow_quad(key, uint32_t(lr), uint32_t(j), LN);       // rows 2 lr, 2 lr + 1 of column j
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) { w0[e] = shadow_pick(hq, e, 0); w1[e] = shadow_pick(hq, e, 1); }
+                } else {
+                    f2v const wO = f2v{__shfl_xor(wMk[0], 8), __shfl_xor(wMk[1], 8)};
+                    w0 = cp ? d2v{wO[0], wO[1]} : d2v{wMk[0], wMk[1]}; w1 = cp ? d2v{wMk[0], wMk[1]} : d2v{wO[0], wO[1]};
+                }
+                if constexpr (EPI == EPI_XPAY_DOT) {          // v9 := A v6; v4 := v8 + beta v4; v4 := v9 + beta v4 (tfqmrgpu_core.hxx:196-202)
+                    d2v const vO = xor8(vMk), vr = cp ? vO : vMk, vi = cp ? vMk : vO;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        R const tr = __builtin_fma(-si[k], ui[e], __builtin_fma(sr[k], ur[e], vr[e]));
+                        R const ti = __builtin_fma(sr[k], ui[e], __builtin_fma(si[k], ur[e], vi[e]));
+                        nr[e] = __builtin_fma(-si[k], ti, __builtin_fma(sr[k], tr, yr[e]));
+                        ni[e] = __builtin_fma(sr[k], ti, __builtin_fma(si[k], tr, yi[e]));
+                    }
+                } else {                                      // v8 := A v6; v5 := alfa v8 + v5 (tfqmrgpu_core.hxx:224-228)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        nr[e] = __builtin_fma(-si[k], yi[e], __builtin_fma(sr[k], yr[e], ur[e]));
+                        ni[e] = __builtin_fma(sr[k], yi[e], __builtin_fma(si[k], yr[e], ui[e]));
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {                 // every lane has both parts: the lanes of plane 0 are the ones that count
+                    double const dr = nr[e], di = ni[e];
+                    part[k][0] = __builtin_fma(-di, w1[e], __builtin_fma(dr, w0[e], part[k][0]));
+                    part[k][1] = __builtin_fma(di, w0[e], __builtin_fma(dr, w1[e], part[k][1]));
+                    if constexpr (EPI == EPI_AXPY_NRM_DOT) part[k][2] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[k][2]));
+                }
+                __builtin_nontemporal_store(yM, (d2v*)((R*)a.Y + yoff));
+                __builtin_nontemporal_store(cp ? ni : nr, (d2v*)((R*)a.e0 + yoff));
+            } else if constexpr (EPI == EPI_RESIDUAL) {       // |A x - b|^2, nothing stored (tfqmrgpu_core.hxx:265-269)
+                uint32_t const bq = a.bOfX ? a.bOfX[y + dBlk[k]] : y + dBlk[k];
+                d2v bM = d2v{0, 0};
+                if (bq != 0xffffffffu) bM = *(d2v const*)((R const*)a.B + size_t(bq) * 2 * P + mine);
+                d2v const bO = xor8(bM), br = cp ? bO : bM, bi = cp ? bM : bO;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    double const dr = yr[e] + R(-1) * br[e], di = yi[e] + R(-1) * bi[e];
+                    part[k][0] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[k][0]));
+                }
+            } else {
+                __builtin_nontemporal_store(yM, (d2v*)((R*)a.Y + yoff));
+            }
+        }
+    }
+    if constexpr (NPL > 0) {
+        // the rows of a column sit 16 lanes apart (lr); lanes 0..7 (plane 0, lr 0) hold the column sums
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                double v = part[k][p];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (lane < 8) s[k][wave][p][lane] = v;
+            }
+        __syncthreads();
+        for (int e = threadIdx.x; e < NB * NPL * LN; e += 256) {
+            int const k = e / (NPL * LN), p = (e / LN) % NPL, jj = e % LN;
+            if (k < nb) {
+                double const sum = ((s[k][0][p][jj] + s[k][1][p][jj]) + s[k][2][p][jj]) + s[k][3][p][jj];
+                uint32_t dc = dChk[0];
+#pragma unroll
+                for (int kk = 1; kk < NB; ++kk) if (kk == k) dc = dChk[kk];
+                write_record<EPI>(a, chunk + dc, LN, p, jj, sum);
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
 // 8 x 32 and 8 x 64 complex<double> on the row-pair-interleaved order: k_spmm_ilv8's tile ([Re A; Im A] x [Re X | Im X], one exchange
 // with the lane 8 further) once per group of 8 block columns.  A wave-wide 16-byte access covers both planes and all 8 rows of ONE
 // column group (8 segments of 128 bytes), so a block product is 1 + LN / 8 loads of 1 KiB (k_spmm_mfma8 on the native order: 2 + 2 LN / 8
@@ -1926,6 +2091,17 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
         if (a.ilv && a.chunkFirst) {
             constexpr bool canHash8 = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
             constexpr bool canFirst = (EPI == EPI_XPAY_DOT);
+            if (a.colBatch) {   // block columns with identical row patterns, multiplied kColBatchMax at a time (tfq_plan.cpp: colBatch; the launch runs over the first columns' chunks)
+                constexpr int NBATCH = kColBatchMax;
+                if (canFirst && a.first) {
+                    if (canHash8 && a.hashV3) k_spmm_ilv8b<EPI, canHash8, NBATCH, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a);
+                    else k_spmm_ilv8b<EPI, false, NBATCH, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a);
+                    return;
+                }
+                if (canHash8 && a.hashV3) k_spmm_ilv8b<EPI, canHash8, NBATCH><<<dim3(nWG), dim3(256), 0, s>>>(a);
+                else k_spmm_ilv8b<EPI, false, NBATCH><<<dim3(nWG), dim3(256), 0, s>>>(a);
+                return;
+            }
             if (canFirst && a.first) {
                 if (canHash8 && a.hashV3) k_spmm_ilv8<EPI, canHash8, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a);
                 else k_spmm_ilv8<EPI, false, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a);
@@ -2041,6 +2217,7 @@ static SpmmArgs spmm_args(int epi, DevPlan const& d) {
     a.m3 = d.m3;
     a.foldPlan = d.fold ? d.self : nullptr;
     a.hashV3 = d.hashV3; a.origCol = d.origCol; a.rowI = d.rowI; a.ilv = d.ilv; a.aOnce = d.aOnce;
+    a.colBatch = d.colBatch; a.colStart = d.colStart; a.colChunkPtr = d.colChunkPtr;
     switch (epi) {
     case EPI_XPAY_DOT:     a.X = d.v6; a.Y = d.v9; a.e0 = d.v4; a.e1 = d.v8; a.sc = d.beta; a.gate = 1; a.first = d.first; break;
     case EPI_AXPY_NRM_DOT: a.X = d.v6; a.Y = d.v8; a.e0 = d.v5; a.sc = d.alfa; a.gate = 1; break;
@@ -2050,16 +2227,22 @@ static SpmmArgs spmm_args(int epi, DevPlan const& d) {
     return a;
 }
 
+// (column batches: one work group per chunk of a batch's FIRST column, in an order of its own)
+static bool batched(DevPlan const& d) { return d.colBatch && !d.fold; }
+
 void spmm_launch(int epi, DevPlan const& d, hipStream_t s) {
     if (epi != EPI_XPAY_DOT && epi != EPI_AXPY_NRM_DOT && epi != EPI_RESIDUAL) return;
-    spmm_dispatch(d.dbl, d.LM, d.LN, epi, spmm_args(epi, d), d.nChunks, s);
+    SpmmArgs a = spmm_args(epi, d);
+    if (batched(d)) a.order = d.orderB; else a.colBatch = nullptr;
+    spmm_dispatch(d.dbl, d.LM, d.LN, epi, a, batched(d) ? d.nChunksB : d.nChunks, s);
 }
 
 // Y = A * X on vectors of the plan (both in the plan's own block and element order), no epilogue, never gated
 void spmm_apply(DevPlan const& d, void const* X, void* Y, hipStream_t s) {
     SpmmArgs a = spmm_args(EPI_NONE, d);
     a.X = X; a.Y = Y; a.gate = 0;
-    spmm_dispatch(d.dbl, d.LM, d.LN, EPI_NONE, a, d.nChunks, s);
+    if (batched(d)) a.order = d.orderB; else a.colBatch = nullptr;
+    spmm_dispatch(d.dbl, d.LM, d.LN, EPI_NONE, a, batched(d) ? d.nChunksB : d.nChunks, s);
 }
 
 template <typename R, int LM, int LN>

@@ -6,6 +6,10 @@
 #include <cstdlib>
 
 namespace tfq {
+// block columns multiplied together at most (tfq_plan.cpp: Plan::colBatch, tfq_spmm.hip: k_spmm_ilv8b; with 4 hipcc does not fit the registers of
+// three waves per SIMD without scratch)
+constexpr int kColBatchMax = 2;
+
 inline int lab_switch(char const* name, int dflt) {
 #ifdef TFQ_LAB
     auto const v = std::getenv(name);
