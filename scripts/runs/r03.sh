@@ -401,5 +401,11 @@ av)
     for v in 1 2 1 2; do echo "$wl TFQMRGPU_BATCH=$v"; TFQMRGPU_BATCH=$v timeout 300 python scripts/ab_fused.py $wl $L 2>&1 | grep -v amdgpu; done
   done
   ;;
+aw)
+  # column batches shipped: the whole GPU suite (with the new bit-identity and multiply tests), config 5 bench lines
+  step 1100 pytest_r03aw.log python -m pytest tests -m gpu -q
+  grep -E "^FAILED|passed|failed" gpurun_out/pytest_r03aw.log | tail -5
+  python bench.py --workload stencil2d_8x8_z --steps 20 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-400
+  ;;
 *) echo "usage: r03.sh <step>; steps:"; grep -E "^[a-z]+\)$" "$0" | tr -d ")" | tr "\n" " "; echo; exit 2 ;;
 esac

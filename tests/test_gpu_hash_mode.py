@@ -179,6 +179,18 @@ def test_tuning_switches_change_code_paths_not_results(tmp_path, name, prec, tol
             assert np.array_equal(got["X"], base["X"]), sw   # these change WHEN things run, never what is added to what
 
 
+@pytest.mark.parametrize("name", ["stencil:40:40:8:8:5:7:5", "stencil:36:36:8:8:2:3:5", "stencil:48:30:8:8:3:11:5"])   # batches (2, 2, 1) | (2) | (2, 1) of block columns
+def test_column_batches_change_no_bit(tmp_path, name):
+    """8 x 8 complex<double>: block columns with identical row patterns are multiplied two at a time (k_spmm_ilv8b: one A fetch for both, plans of more
+    than 128 chunks; profiles/r03_column_batches.txt).  Chunks, records and every sum are those of the one-column kernel: against the lab build with
+    TFQMRGPU_BATCH=1 (batches off) the solve must not differ in a single bit -- iteration count, bound history, residual, solution."""
+    on = _worker(tmp_path, "batched", name, "z", 1e-9)
+    off = _worker(tmp_path, "single", name, "z", 1e-9, TFQMRGPU_BATCH=1)
+    assert int(on["status"]) == int(off["status"]) == 0 and int(on["iterations"]) == int(off["iterations"])
+    assert np.array_equal(on["history"], off["history"]) and float(on["residual"]) == float(off["residual"])
+    assert np.array_equal(on["X"], off["X"])
+
+
 def test_plain_mode_xcd_mapping(tmp_path):
     """lab switch TFQMRGPU_PLAIN_XCD (native-API multiply: contiguous eighths of the caller's Y blocks per XCD instead of round-robin work
     groups; profiles/r03_native_multiply.txt): which work group computes a Y block changes, the product does not -- on BASELINE config 1's plan."""

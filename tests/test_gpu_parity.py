@@ -566,6 +566,25 @@ def test_apply_operator_on_plan_data(oracle, prec, shape):
     assert np.abs(got - want).max() <= eps * LM * 6 * max(1.0, np.abs(want).max())
 
 
+def test_apply_operator_with_column_batches(oracle):
+    """8 x 8 complex<double>, three block columns with the same row pattern on a plan of more than 128 chunks: the multiply takes the first two
+    columns together and the third alone (k_spmm_ilv8b); X := A*X against the oracle's product, as in the test above"""
+    LM = LN = 8
+    pr = PR.stencil_2d(48, 30, LM, LN, 3, seed=11)
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-1, 1, (pr.nnzbX, LM, LN)) + 1j * rng.uniform(-1, 1, (pr.nnzbX, LM, LN))
+    an = oracle.analyse(pr)
+    want = oracle.from_native(oracle.spmm("z", LM, LN, an["starts"], an["pairs"], oracle.a_native(pr.A, np.float64), oracle.to_native(X, np.float64)))
+    with T.Solver() as s:
+        s.create_plan(pr)
+        s.set_buffer(nbytes=s.buffer_size(LM, LN, "z"))
+        s.set_matrix("A", pr.A)
+        s.set_matrix("X", X)
+        s.apply_operator()
+        got = s.get_matrix()
+    assert np.abs(got - want).max() <= 1e-13 * LM * 6 * max(1.0, np.abs(want).max())
+
+
 def test_three_product_form_is_opt_in(torch_cuda, oracle):
     """32 x 32 complex<double>: the default multiply forms a complex product from four real ones like the reference, so an
     imaginary part 1e-8 times smaller than the real part keeps its digits (up to r02 the three-product form was the default and lost 8
