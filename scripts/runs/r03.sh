@@ -407,5 +407,12 @@ aw)
   grep -E "^FAILED|passed|failed" gpurun_out/pytest_r03aw.log | tail -5
   python bench.py --workload stencil2d_8x8_z --steps 20 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-400
   ;;
+ax)
+  # column batches of up to FOUR columns at two waves per SIMD (temporary build: kColBatchMax = 4, launch bound 2): lab TFQMRGPU_BATCH = 1 | 2 | 4 on config 5
+  L=tfqmrgpu_amd/lib/libtfQMRgpu_lab.so
+  for wl in stencil2d_8x8_z st:8:8:z:512:512:8; do
+    for v in 1 2 4 1 2 4; do echo "$wl TFQMRGPU_BATCH=$v"; TFQMRGPU_BATCH=$v timeout 300 python scripts/ab_fused.py $wl $L 2>&1 | grep -v amdgpu; done
+  done
+  ;;
 *) echo "usage: r03.sh <step>; steps:"; grep -E "^[a-z]+\)$" "$0" | tr -d ")" | tr "\n" " "; echo; exit 2 ;;
 esac
