@@ -414,5 +414,10 @@ ax)
     for v in 1 2 4 1 2 4; do echo "$wl TFQMRGPU_BATCH=$v"; TFQMRGPU_BATCH=$v timeout 300 python scripts/ab_fused.py $wl $L 2>&1 | grep -v amdgpu; done
   done
   ;;
+az)
+  # 16 x 16 complex<float> (k_spmm_ilv16f; the shape and precision of the reference's bench multi default): the operand-skipping probes 64 | 128 | 192
+  export AB_MAXIT=30
+  timeout 800 python scripts/ab_fused.py st:16:16:c:96:96:16 tfqmrgpu_amd/lib/libtfQMRgpu.so scripts/bin/libtfQMRgpu_p64.so scripts/bin/libtfQMRgpu_p128.so scripts/bin/libtfQMRgpu_p192.so tfqmrgpu_amd/lib/libtfQMRgpu.so 2>&1 | grep -v amdgpu
+  ;;
 *) echo "usage: r03.sh <step>; steps:"; grep -E "^[a-z]+\)$" "$0" | tr -d ")" | tr "\n" " "; echo; exit 2 ;;
 esac

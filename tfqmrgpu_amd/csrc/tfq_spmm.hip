@@ -868,9 +868,11 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
     auto fetch = [&](Ops& o, uint32_t q) __attribute__((always_inline)) {
         R const* Ab = A0 + size_t(pairs[2 * size_t(q)]) * 2 * P;
         R const* Xb = X0 + size_t(pairs[2 * size_t(q) + 1]) * 2 * P;
+        if (!(TFQ_PROBE & 64) || (q & 6) == 0) {   // (probes: 3 of 4 fetches skipped, stale registers)
         if constexpr (ANT) { o.ar = __builtin_nontemporal_load((f4v const*)Ab); o.ai = __builtin_nontemporal_load((f4v const*)(Ab + P)); }
         else { o.ar = *(f4v const*)Ab; o.ai = *(f4v const*)(Ab + P); }
-        o.xr = *(f4v const*)Xb; o.xi = *(f4v const*)(Xb + P);
+        }
+        if (!(TFQ_PROBE & 128) || (q & 6) == 0) { o.xr = *(f4v const*)Xb; o.xi = *(f4v const*)(Xb + P); }
     };
     for (uint32_t u = wave; u < last - first; u += 4) {
         uint32_t const y = first + u;
@@ -888,6 +890,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
         };
         uint32_t const q0 = starts[y], q1 = starts[y + 1];
         Ops o0, o1;
+        if constexpr ((TFQ_PROBE & 192) != 0) { o0.ar = f4v{1e-3f * lane, 1e-3f, 2e-3f, 3e-3f}; o0.ai = o0.ar; o0.xr = o0.ar; o0.xi = o0.ar; o1 = o0; }   // (probes: defined contents)
         constexpr bool EPI_FIRST = true;   // epilogue operands requested in front of the first products' operands: -1 % (profiles/r02_ab_traversal.txt)
         if constexpr (!EPI_FIRST) {
             if (q0 < q1) fetch(o0, q0);
