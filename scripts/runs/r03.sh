@@ -419,5 +419,11 @@ az)
   export AB_MAXIT=30
   timeout 800 python scripts/ab_fused.py st:16:16:c:96:96:16 tfqmrgpu_amd/lib/libtfQMRgpu.so scripts/bin/libtfQMRgpu_p64.so scripts/bin/libtfQMRgpu_p128.so scripts/bin/libtfQMRgpu_p192.so tfqmrgpu_amd/lib/libtfQMRgpu.so 2>&1 | grep -v amdgpu
   ;;
+ba)
+  # column batches: 2 | 3 | 4 block products in flight per wave (variant builds -DTFQ_B8_DEPTH)
+  for wl in stencil2d_8x8_z st:8:8:z:512:512:8; do
+    timeout 600 python scripts/ab_fused.py $wl tfqmrgpu_amd/lib/libtfQMRgpu.so scripts/bin/libtfQMRgpu_d3.so scripts/bin/libtfQMRgpu_d4.so tfqmrgpu_amd/lib/libtfQMRgpu.so scripts/bin/libtfQMRgpu_d3.so scripts/bin/libtfQMRgpu_d4.so 2>&1 | grep -v amdgpu
+  done
+  ;;
 *) echo "usage: r03.sh <step>; steps:"; grep -E "^[a-z]+\)$" "$0" | tr -d ")" | tr "\n" " "; echo; exit 2 ;;
 esac

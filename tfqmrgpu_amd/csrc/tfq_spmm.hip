@@ -1366,7 +1366,10 @@ __global__ __launch_bounds__(256, 3) void k_spmm_ilv8b(SpmmArgs a) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) acc[k] = T4{0, 0, 0, 0};
         uint32_t const q0 = starts[y], nq = starts[y + 1] - q0;
-        constexpr int DEPTH = 2;
+#ifndef TFQ_B8_DEPTH
+#define TFQ_B8_DEPTH 2
+#endif
+        constexpr int DEPTH = TFQ_B8_DEPTH;   // block products in flight (variant builds: 3, 4)
         Ops o[DEPTH];
 #pragma unroll
         for (int dd = 0; dd < DEPTH; ++dd) if (uint32_t(dd) < nq) fetch(o[dd], q0 + dd);
