@@ -425,5 +425,11 @@ ba)
     timeout 600 python scripts/ab_fused.py $wl tfqmrgpu_amd/lib/libtfQMRgpu.so scripts/bin/libtfQMRgpu_d3.so scripts/bin/libtfQMRgpu_d4.so tfqmrgpu_amd/lib/libtfQMRgpu.so scripts/bin/libtfQMRgpu_d3.so scripts/bin/libtfQMRgpu_d4.so 2>&1 | grep -v amdgpu
   done
   ;;
+bb)
+  # soak: 100 solves each must give the same bits -- config 5 (column pairs), P2 in 'm' (new cycle policy), a folded small system
+  timeout 500 python scripts/soak.py stencil2d_8x8_z 100 2>&1 | grep -v amdgpu | tail -2
+  timeout 500 python scripts/soak.py fd2d_16x16_z 60 m 2>&1 | grep -v amdgpu | tail -2
+  timeout 300 python scripts/soak.py st:16:16:z:8:8:2 200 2>&1 | grep -v amdgpu | tail -2
+  ;;
 *) echo "usage: r03.sh <step>; steps:"; grep -E "^[a-z]+\)$" "$0" | tr -d ")" | tr "\n" " "; echo; exit 2 ;;
 esac
