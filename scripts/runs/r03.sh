@@ -431,5 +431,9 @@ bb)
   timeout 500 python scripts/soak.py fd2d_16x16_z 60 m 2>&1 | grep -v amdgpu | tail -2
   timeout 300 python scripts/soak.py st:16:16:z:8:8:2 200 2>&1 | grep -v amdgpu | tail -2
   ;;
+bd)
+  # where the ~20 us of a small multiply go: stamps of one wave per work group of k_spmm_ilv16 (variant build -DTFQ_LAB_STAMPS), scripts/wg_timeline.py
+  timeout 300 python scripts/wg_timeline.py 2>&1 | grep -v amdgpu
+  ;;
 *) echo "usage: r03.sh <step>; steps:"; grep -E "^[a-z]+\)$" "$0" | tr -d ")" | tr "\n" " "; echo; exit 2 ;;
 esac

@@ -49,6 +49,21 @@ extern "C" int tfqmrgpuLab_clockRecord(unsigned long long* threeCountersOnTheDev
 }
 #endif
 
+#ifdef TFQ_LAB_STAMPS
+// builds with -DTFQ_LAB_STAMPS only (scripts/build_variant.sh stamps -DTFQ_LAB -DTFQ_LAB_STAMPS): a timeline of ONE wave per work group of k_spmm_ilv16 in the constant
+// 100 MHz clock (s_memrealtime): [work group][8] = entry | state known | chunk known | pair range known | first operands + epilogue operands landed | products done |
+// stores issued | records written.  The waits in front of the stamps are part of the variant: it is a diagnostic of latency-bound (small) launches, scripts/wg_timeline.py.
+__device__ unsigned long long* g_tfqStamps = nullptr;
+extern "C" int tfqmrgpuLab_stamps(unsigned long long* eightPerWorkGroupOnTheDevice) {
+    return int(hipMemcpyToSymbol(HIP_SYMBOL(g_tfqStamps), &eightPerWorkGroupOnTheDevice, sizeof eightPerWorkGroupOnTheDevice));
+}
+#define TFQ_KEEP2(a, b) asm volatile("" :: "s"(a), "s"(b))
+#define TFQ_STAMP(k, waits) do { asm volatile(waits ::: "memory"); if (g_tfqStamps && 0 == threadIdx.x) g_tfqStamps[size_t(blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define TFQ_KEEP2(a, b) do {} while (0)
+#define TFQ_STAMP(k, waits) do {} while (0)
+#endif
+
 namespace tfq {
 
 struct SpmmArgs {
@@ -665,7 +680,9 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
 #ifdef TFQ_LAB_CLOCK
     long long const labC0 = clock64(), labW0 = wall_clock64();
 #endif
+    TFQ_STAMP(0, "");
     if (gate_closed(a)) return;
+    TFQ_STAMP(1, "s_waitcnt lgkmcnt(0)");
     using R = double;
     constexpr int LN = 16, P = 256, NPL = EpiPlanes<EPI>::N;
     constexpr bool UPD = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
@@ -678,6 +695,8 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
     CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
     uint32_t const chunk = (a.order && !(TFQ_PROBE & 2)) ? a.order[blockIdx.x] : blockIdx.x;   // XCD-aware launch order (tfq_plan.cpp)
     uint32_t const first = a.chunkFirst[chunk], last = a.chunkFirst[chunk + 1], col = a.chunkCol[chunk];
+    TFQ_KEEP2(first, last); TFQ_KEEP2(col, col);
+    TFQ_STAMP(2, "s_waitcnt lgkmcnt(0)");
     R sr = 0, si = 0;
     if constexpr (UPD) { sr = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + lc]; si = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + lc]; }
     double part[NPL > 0 ? NPL : 1] = {};
@@ -716,6 +735,8 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
                 }
         };
         uint32_t const q0 = starts[y], q1 = (TFQ_PROBE & 1) ? q0 : starts[y + 1];
+        TFQ_KEEP2(q0, q1);
+        TFQ_STAMP(3, "s_waitcnt lgkmcnt(0)");
         Ops o0, o1;
         if constexpr ((TFQ_PROBE & 192) != 0) {   // (probes: defined contents for the skipped fetches)
             for (int h = 0; h < 2; ++h) { o0.ar[h] = o0.ai[h] = o0.xr[h] = o0.xi[h] = o1.ar[h] = o1.ai[h] = o1.xr[h] = o1.xi[h] = d2v{1e-3 * lane, 1e-3}; }
@@ -749,6 +770,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
         // (r03, profiles/r03_ab_exact_waits.txt: the conditional prefetches make the compiler wait with vmcnt(0) in front of every pair of
         //  products; both forms with exact waits -- prefetch index clamped to the last product, or straight-line tails behind a loop that
         //  always prefetches -- measured 4-8 % SLOWER on P2: redundant cache-hot fetches, or 192 VGPRs = two waves per SIMD)
+        TFQ_STAMP(4, "s_waitcnt vmcnt(0)");
         uint32_t q = q0;
         for (; q + 2 <= q1; q += 2) {
             mma(o0);
@@ -757,6 +779,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
             if (q + 3 < q1) fetch(o1, q + 3);
         }
         if (q < q1) mma(o0);
+        TFQ_STAMP(5, "s_nop 0");
 
         uint32_t bq = 0xffffffffu;
         if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX ? a.bOfX[y] : y;
@@ -807,6 +830,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
             }
         }
     }
+    TFQ_STAMP(6, "");
     if constexpr (NPL > 0 && (TFQ_PROBE & 8)) { if (part[0] == 1.2345e300 && part[1] == 5.4321e300) write_record<EPI>(a, chunk, LN, 0, lane & 15, part[NPL - 1]); }
     else if constexpr (NPL > 0) {
         // rows live on lane / 16 (and registers): add the four lane groups, then the four waves in order
@@ -825,6 +849,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
         }
         if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
     }
+    TFQ_STAMP(7, "s_waitcnt vmcnt(0) lgkmcnt(0)");
 #ifdef TFQ_LAB_CLOCK
     if (g_tfqClockRec && 0 == threadIdx.x) {
         atomicAdd(g_tfqClockRec, (unsigned long long)(clock64() - labC0));
