@@ -435,5 +435,9 @@ bd)
   # where the ~20 us of a small multiply go: stamps of one wave per work group of k_spmm_ilv16 (variant build -DTFQ_LAB_STAMPS), scripts/wg_timeline.py
   timeout 300 python scripts/wg_timeline.py 2>&1 | grep -v amdgpu
   ;;
+be)
+  # the same timeline under LOAD: P2, plain multiply and the last launches of the two fused multiplies of a solve
+  for e in 0 1 2; do WG_EPI=$e timeout 300 python scripts/wg_timeline.py fd2d_16x16_z 2>&1 | grep -v amdgpu; done
+  ;;
 *) echo "usage: r03.sh <step>; steps:"; grep -E "^[a-z]+\)$" "$0" | tr -d ")" | tr "\n" " "; echo; exit 2 ;;
 esac

@@ -54,13 +54,19 @@ extern "C" int tfqmrgpuLab_clockRecord(unsigned long long* threeCountersOnTheDev
 // 100 MHz clock (s_memrealtime): [work group][8] = entry | state known | chunk known | pair range known | first operands + epilogue operands landed | products done |
 // stores issued | records written.  The waits in front of the stamps are part of the variant: it is a diagnostic of latency-bound (small) launches, scripts/wg_timeline.py.
 __device__ unsigned long long* g_tfqStamps = nullptr;
-extern "C" int tfqmrgpuLab_stamps(unsigned long long* eightPerWorkGroupOnTheDevice) {
+__device__ int g_tfqStampEpi = 0;           // which instance stamps: the epilogue number (0: the plain multiply)
+extern "C" int tfqmrgpuLab_stamps(unsigned long long* eightPerWorkGroupOnTheDevice, int epilogue) {
+    if (hipSuccess != hipMemcpyToSymbol(HIP_SYMBOL(g_tfqStampEpi), &epilogue, sizeof epilogue)) return 1;
     return int(hipMemcpyToSymbol(HIP_SYMBOL(g_tfqStamps), &eightPerWorkGroupOnTheDevice, sizeof eightPerWorkGroupOnTheDevice));
 }
 #define TFQ_KEEP2(a, b) asm volatile("" :: "s"(a), "s"(b))
-#define TFQ_STAMP(k, waits) do { asm volatile(waits ::: "memory"); if (g_tfqStamps && 0 == threadIdx.x) g_tfqStamps[size_t(blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+// (work groups that the gate turns away do not stamp: every launch of the chosen instance that does work overwrites the one before, the last one stays)
+#define TFQ_STAMP_ENTRY unsigned long long const stampEntry_ = wall_clock64();
+#define TFQ_STAMP(k, waits) do { asm volatile(waits ::: "memory"); if (g_tfqStamps && g_tfqStampEpi == EPI && 0 == threadIdx.x) { \
+    if (1 == (k)) g_tfqStamps[size_t(blockIdx.x) * 8] = stampEntry_; g_tfqStamps[size_t(blockIdx.x) * 8 + (k)] = wall_clock64(); } } while (0)
 #else
 #define TFQ_KEEP2(a, b) do {} while (0)
+#define TFQ_STAMP_ENTRY
 #define TFQ_STAMP(k, waits) do {} while (0)
 #endif
 
@@ -680,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
 #ifdef TFQ_LAB_CLOCK
     long long const labC0 = clock64(), labW0 = wall_clock64();
 #endif
-    TFQ_STAMP(0, "");
+    TFQ_STAMP_ENTRY
     if (gate_closed(a)) return;
     TFQ_STAMP(1, "s_waitcnt lgkmcnt(0)");
     using R = double;
