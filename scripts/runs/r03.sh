@@ -439,5 +439,10 @@ be)
   # the same timeline under LOAD: P2, plain multiply and the last launches of the two fused multiplies of a solve
   for e in 0 1 2; do WG_EPI=$e timeout 300 python scripts/wg_timeline.py fd2d_16x16_z 2>&1 | grep -v amdgpu; done
   ;;
+bf)
+  # where requests queue: L1 -> L2 and L2 -> fabric read latencies per kernel from PMC (scripts/pmc_latency.sh)
+  timeout 1000 bash scripts/pmc_latency.sh gpurun_out/pmc_lat > gpurun_out/r03_pmc_latency.txt 2>&1
+  cat gpurun_out/r03_pmc_latency.txt | cut -c1-230
+  ;;
 *) echo "usage: r03.sh <step>; steps:"; grep -E "^[a-z]+\)$" "$0" | tr -d ")" | tr "\n" " "; echo; exit 2 ;;
 esac
