@@ -34,14 +34,22 @@ s.apply_operator(20); torch.cuda.synchronize()
 e0.record(); s.apply_operator(20); e1.record(); torch.cuda.synchronize()
 it = sum(v[1] / v[0] for k, v in acc.items() if k != "probe" and v[0])
 g = lambda k: acc[k][1] / max(1, acc[k][0])
-print("%%-28s st %%d it %%d res %%.3e | spmm_v4_dot %%.4f spmm_v5_nrm_dot %%.4f x_v6_v7 %%.4f xpay %%.4f v5_nrm %%.4f | multiply %%.4f | iteration %%.4f ms | solve %%.3f ms" %% (
-    os.path.basename(os.environ.get("TFQMRGPU_LIB", "default")), st, info["iterations"], info["residual"], g("spmm_v4_dot"), g("spmm_v5_nrm_dot"), g("x_v6_v7"), g("xpay_v6"), g("v5_nrm"),
+print("%%-44s st %%d it %%d res %%.3e | spmm_v4_dot %%.4f spmm_v5_nrm_dot %%.4f x_v6_v7 %%.4f xpay %%.4f v5_nrm %%.4f | multiply %%.4f | iteration %%.4f ms | solve %%.3f ms" %% (
+    os.environ.get("AB_TAG", "default"), st, info["iterations"], info["residual"], g("spmm_v4_dot"), g("spmm_v5_nrm_dot"), g("x_v6_v7"), g("xpay_v6"), g("v5_nrm"),
     e0.elapsed_time(e1) / 20, it, solve_ms), flush=True)
+if os.environ.get("AB_ALL"):
+    print("    " + " ".join("%%s %%.4f" %% (k, g(k)) for k in acc), flush=True)
 s.close()
 ''' % ROOT
 wl = sys.argv[1]
 for lib in sys.argv[2:]:
     env = dict(os.environ)
+    lib, _, switches = lib.partition("@")          # lib@TFQMRGPU_X=1,TFQMRGPU_Y=2: tuning switches of a LAB build (tfq_switch.hpp)
+    if lib == "lab":
+        lib = "tfqmrgpu_amd/lib/libtfQMRgpu_lab.so"
     if lib != "default":
         env["TFQMRGPU_LIB"] = os.path.join(ROOT, lib)
+    for kv in filter(None, switches.split(",")):
+        k, _, v = kv.partition("="); env[k] = v
+    env["AB_TAG"] = os.path.basename(lib) + ("@" + switches if switches else "")
     subprocess.call([sys.executable, "-c", CHILD, wl], env=env)

@@ -1,0 +1,77 @@
+#!/bin/bash
+# Every GPU call of round 4 as one parametrised script: gpurun --timeout N -- bash scripts/runs/r04.sh <step>.  A step is what was one
+# gpurun call; its comment says what it measured, profiles/r04_*.txt hold what came out (the records name the steps as "r04.sh <step>").
+source scripts/gpu_steps.sh
+case "$1" in
+a)
+  # round 4, first call: one wave per chunk with a pipeline across its Y blocks (k_spmm_ilv16p): bit-identity with k_spmm_ilv16, A/B on P2
+  step 600 r04a_bits.txt python scripts/pipe_bits.py
+  cat gpurun_out/r04a_bits.txt
+  step 600 r04a_ab.txt python scripts/ab_fused.py fd2d_16x16_z lab@TFQMRGPU_PIPE=0 lab@TFQMRGPU_PIPE=1 lab@TFQMRGPU_PIPE=1,TFQMRGPU_PIPE_SORT=1 lab@TFQMRGPU_PIPE=0 default
+  cat gpurun_out/r04a_ab.txt
+  ;;
+b)
+  # one wave per chunk: is it the number of chunks in flight per XCD (L2 working set)?  unused LDS limits the work groups per CU: 100 KiB -> 1, 60 -> 2, 40 -> 3
+  step 900 r04b_ab.txt python scripts/ab_fused.py fd2d_16x16_z lab@TFQMRGPU_PIPE=0 lab@TFQMRGPU_PIPE=1,TFQMRGPU_PIPE_LDS_KIB=100 lab@TFQMRGPU_PIPE=1,TFQMRGPU_PIPE_LDS_KIB=60 lab@TFQMRGPU_PIPE=1,TFQMRGPU_PIPE_LDS_KIB=40 lab@TFQMRGPU_PIPE=1
+  cat gpurun_out/r04b_ab.txt
+  ;;
+c)
+  # PMC of the two forms of the 16 x 16 z multiply on P2: one wave per Y block (PIPE=0) | one wave per chunk, pipelined (PIPE=1, two work groups per CU)
+  export TFQMRGPU_LIB=$GRAFT_REPO_ROOT/tfqmrgpu_amd/lib/libtfQMRgpu_lab.so
+  export TFQMRGPU_PIPE=0
+  bash scripts/pmc_collect.sh gpurun_out/r04c_pmc0 > gpurun_out/r04c_pmc0.log 2>&1
+  python3 scripts/pmc_summary.py gpurun_out/r04c_pmc0 > gpurun_out/r04c_pmc0.json
+  export TFQMRGPU_PIPE=1 TFQMRGPU_PIPE_LDS_KIB=60
+  bash scripts/pmc_collect.sh gpurun_out/r04c_pmc1 > gpurun_out/r04c_pmc1.log 2>&1
+  python3 scripts/pmc_summary.py gpurun_out/r04c_pmc1 > gpurun_out/r04c_pmc1.json
+  rm -rf gpurun_out/r04c_pmc0 gpurun_out/r04c_pmc1
+  tail -3 gpurun_out/r04c_pmc0.log gpurun_out/r04c_pmc1.log
+  ;;
+d)
+  # one wave per chunk: 2 | 3 | 4 operand sets in flight per wave x work groups per CU (unused LDS: 100 KiB -> 1, 60 -> 2)
+  step 900 r04d_ab.txt python scripts/ab_fused.py fd2d_16x16_z lab@TFQMRGPU_PIPE=0 lab@TFQMRGPU_PIPE_NSET=3 lab@TFQMRGPU_PIPE_NSET=3,TFQMRGPU_PIPE_LDS_KIB=100 lab@TFQMRGPU_PIPE_NSET=4 lab@TFQMRGPU_PIPE_NSET=4,TFQMRGPU_PIPE_LDS_KIB=60 lab@TFQMRGPU_PIPE_NSET=2,TFQMRGPU_PIPE_LDS_KIB=60
+  cat gpurun_out/r04d_ab.txt
+  ;;
+e)
+  # 8 x 8 z: column batches of four at work-group level, one wave per column (k_spmm_ilv8c): bit-identity, A/B on config 5
+  step 900 r04e_bits.log python -m pytest tests/test_gpu_hash_mode.py -q -x -k "column_batches"
+  step 900 r04e_ab.txt python scripts/ab_fused.py stencil2d_8x8_z lab@TFQMRGPU_BATCH_WIDE=0 lab@TFQMRGPU_BATCH_WIDE=1 lab@TFQMRGPU_BATCH=1 lab@TFQMRGPU_BATCH_WIDE=0 lab@TFQMRGPU_BATCH_WIDE=1
+  cat gpurun_out/r04e_ab.txt
+  ;;
+f)
+  # PMC of config 5 (8 x 8 z, 256^2 rows, 8 columns) with the shipped column pairs (k_spmm_ilv8b): what the multiply moves through the fabric
+  export TFQMRGPU_LIB=$GRAFT_REPO_ROOT/tfqmrgpu_amd/lib/libtfQMRgpu_lab.so
+  export TFQMRGPU_BATCH_WIDE=0
+  bash scripts/pmc_collect.sh gpurun_out/r04f_pmc stencil2d_8x8_z > gpurun_out/r04f_pmc.log 2>&1
+  python3 scripts/pmc_summary.py gpurun_out/r04f_pmc > gpurun_out/r04f_pmc.json
+  rm -rf gpurun_out/r04f_pmc
+  tail -n 3 gpurun_out/r04f_pmc.log
+  ;;
+g)
+  # k_v5_nrm's record sum with its LDS reads in batches (chunk_reduce), column sums with 24 | 12 records in flight: bits unchanged? times?
+  step 900 r04g_tests.log python -m pytest tests/test_gpu_hash_mode.py tests/test_gpu_parity.py -q -x
+  step 600 r04g_ab.txt python scripts/ab_fused.py fd2d_16x16_z scripts/bin/libtfQMRgpu_r03.so default scripts/bin/libtfQMRgpu_r03.so default
+  cat gpurun_out/r04g_ab.txt
+  ;;
+h)
+  # the same A/B with every kernel class listed (AB_ALL=1): the column kernels with 24 | 12 records in flight
+  export AB_ALL=1
+  step 600 r04h_ab.txt python scripts/ab_fused.py fd2d_16x16_z scripts/bin/libtfQMRgpu_r03.so default scripts/bin/libtfQMRgpu_r03.so default
+  cat gpurun_out/r04h_ab.txt
+  ;;
+i)
+  # column sums with 16 records in flight and a predicated tail (bits unchanged?), the Fortran example's three cases (A 'n', X 'n', B 't')
+  export AB_ALL=1
+  step 600 r04i_fortran.log python -m pytest tests/test_fortran.py -q -x
+  cat gpurun_out/r04i_fortran.log | tail -n 20
+  step 600 r04i_ab.txt python scripts/ab_fused.py fd2d_16x16_z scripts/bin/libtfQMRgpu_r03.so default scripts/bin/libtfQMRgpu_r03.so default
+  cat gpurun_out/r04i_ab.txt
+  step 900 r04i_tests.log python -m pytest tests/test_gpu_hash_mode.py tests/test_gpu_parity.py -q -x
+  ;;
+j)
+  # the final form of k_spmm_ilv16p (counted loop, NSET operand sets) against k_spmm_ilv16, bit by bit
+  step 900 r04j_bits.txt python scripts/pipe_bits.py
+  cat gpurun_out/r04j_bits.txt
+  ;;
+*) echo "unknown step $1"; exit 1;;
+esac

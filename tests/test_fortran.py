@@ -13,18 +13,19 @@ FDIR = os.path.join(ROOT, "tfqmrgpu_amd", "fortran")
 LIBDIR = os.path.join(ROOT, "tfqmrgpu_amd", "lib")
 
 
-def _build(tmp_path):
+def _build(tmp_path, program="check_module"):
     if not os.path.exists(FLANG):
         pytest.skip("no Fortran compiler (amdflang) in this image")
-    exe = str(tmp_path / "check_module")
+    exe = str(tmp_path / program)
     subprocess.check_call([FLANG, "-cpp", "-c", os.path.join(FDIR, "tfqmrgpu.F90"), "-o", str(tmp_path / "tfqmrgpu.o")], cwd=tmp_path)
-    subprocess.check_call([FLANG, "-cpp", os.path.join(FDIR, "check_module.F90"), str(tmp_path / "tfqmrgpu.o"),
+    subprocess.check_call([FLANG, "-cpp", os.path.join(FDIR, program + ".F90"), str(tmp_path / "tfqmrgpu.o"),
                            "-L" + LIBDIR, "-ltfQMRgpu", "-Wl,-rpath," + LIBDIR, "-o", exe], cwd=tmp_path)
     return exe
 
 
-def test_module_and_caller_compile_and_link(tmp_path):
-    exe = _build(tmp_path)
+@pytest.mark.parametrize("program", ["check_module", "check_example"])
+def test_module_and_caller_compile_and_link(tmp_path, program):
+    exe = _build(tmp_path, program)
     assert os.path.exists(exe) and os.path.exists(tmp_path / "tfqmrgpu.mod")
 
 
@@ -35,3 +36,17 @@ def test_fortran_caller_solves_dense_system(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "check_module: OK" in r.stdout
+
+
+@pytest.mark.gpu
+def test_fortran_example_cases(tmp_path):
+    """The three cases of the reference's Fortran example (example/tfqmrgpu_Fortran_example.F90:22-46: one 32 x 32 block, a full 4 x 4
+    pattern of 16 x 16 blocks, a banded 4 x 4 pattern of 4 x 4 blocks) with ITS flags -- A 'n', X 'n', B 't', one array for all three --
+    and its dense check (:108-126): cases 1 and 2 max|A X - B| < 1e-8 (the reference's CPU build fails this check with 1.3,
+    its CPU multiply reads A untransposed), case 3 has to run through."""
+    exe = _build(tmp_path, "check_example")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "check_example: OK" in r.stdout
+    dev = [float(v) for v in [l for l in r.stdout.splitlines() if "max|A*X - B| =  " in l or l.startswith("# check_example: max")][-1].split("=")[1].split()]
+    assert dev[0] < 1e-8 and dev[1] < 1e-8 and dev[2] >= 0, dev

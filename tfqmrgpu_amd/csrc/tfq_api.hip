@@ -48,6 +48,8 @@ DevPlan resolve(Plan const& p) {
     d.subset = (uint32_t*)at(p.wSubset); d.bColPtr = (uint32_t*)at(p.wBColPtr); d.bList = (uint32_t*)at(p.wBList);
     d.u2i = (uint32_t*)at(p.wU2I); d.rowI = (uint32_t*)at(p.wRowI); d.origCol = (int32_t*)at(p.wOrigCol);
     d.colBatch = p.colBatch.empty() ? nullptr : (uint8_t const*)at(p.wColBatch);
+    d.orderP = p.chunks.orderP.empty() ? nullptr : (uint32_t const*)at(p.wOrderP); d.nWGp = uint32_t(p.chunks.orderP.size() / 4);
+    d.orderC = p.chunks.orderC.empty() ? nullptr : (uint32_t const*)at(p.wOrderC); d.nChunksC = uint32_t(p.chunks.orderC.size());
     d.orderB = p.colBatch.empty() ? nullptr : (uint32_t const*)at(p.wOrderB); d.nChunksB = uint32_t(p.chunks.orderB.size());
     return d;
 }
@@ -720,6 +722,8 @@ tfqmrgpuStatus_t tfqmrgpu_bsrsv_setBuffer(tfqmrgpuHandle_t handle, tfqmrgpuBsrsv
     if ((st = up(p->wColStart, p->colStart.data(), p->colStart.size() * 4))) return st;
     if ((st = up(p->wOrigCol, orig.data(), orig.size() * 4))) return st;
     if (!p->colBatch.empty() && (st = up(p->wColBatch, p->colBatch.data(), p->colBatch.size()))) return st;
+    if (!c.orderP.empty() && (st = up(p->wOrderP, c.orderP.data(), c.orderP.size() * 4))) return st;
+    if (!c.orderC.empty() && (st = up(p->wOrderC, c.orderC.data(), c.orderC.size() * 4))) return st;
     if (!p->colBatch.empty() && (st = up(p->wOrderB, c.orderB.data(), c.orderB.size() * 4))) return st;
     if ((st = up(p->wBofX, p->bOfX.data(), p->bOfX.size() * 4))) return st;
     if ((st = up(p->wStarts, p->starts_i.data(), p->starts_i.size() * 4))) return st;

@@ -24,25 +24,24 @@ struct ColScratch { double s[512]; double rec[2][64]; double s0[256], s1[256]; i
 template <int LN, int NPL>
 __device__ inline void column_sum(double const* part, uint32_t c0, uint32_t c1, double* s, double (&res)[NPL]) {
     constexpr int G = 256 / LN;      // lane groups: group g takes records c0+g, c0+g+G, ...
-    constexpr int U = 8;             // records in flight per lane (independent loads; the order of the sum stays fixed)
+    constexpr int U = 16;            // records in flight per lane (independent loads; the order of the sum stays fixed).  r04: every batch is predicated, so the
+                                     // tail of a column is a batch too (r01-r03: 8 in flight, and up to 7 records one after the other behind the last full batch;
+                                     // 24 | 12 in flight with that serial tail measured slower: P2 has 705 records per column, 44 per lane group)
     int const t = threadIdx.x, g = t / LN, j = t % LN;
     double acc[NPL] = {};
     if (g < G) {
-        uint32_t c = c0 + g;
-        for (; c + (U - 1) * G < c1; c += U * G) {
+        for (uint32_t c = c0 + g; c < c1; c += U * G) {
             double v[U][NPL];
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) v[u][p] = part[(size_t(c + u * G) * NPL + p) * LN + j];
+                for (int p = 0; p < NPL; ++p) v[u][p] = (c + u * G < c1) ? part[(size_t(c + u * G) * NPL + p) * LN + j] : 0.;
 #pragma unroll
             for (int u = 0; u < U; ++u)
+                if (c + u * G < c1)
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) acc[p] += v[u][p];
+                    for (int p = 0; p < NPL; ++p) acc[p] += v[u][p];
         }
-        for (; c < c1; c += G)
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) acc[p] += part[(size_t(c) * NPL + p) * LN + j];
     }
     __syncthreads();
     if (g < G)

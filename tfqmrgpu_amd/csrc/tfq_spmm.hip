@@ -94,6 +94,8 @@ struct SpmmArgs {
     int m3;                            // double shapes above 16 x 16: three real products per complex one (tfqmrgpuExt_setThreeProductMultiply)
     DevPlan const* foldPlan;           // not null: the column operation that consumes this launch's records runs in its tail (tfq_colops.hpp)
     uint8_t const* colBatch; uint32_t const* colStart; uint32_t const* colChunkPtr;   // k_spmm_ilv8b: (batch size << 4) | position per block column; block / chunk ranges of the columns
+    int wide;                          // this launch runs over DevPlan::orderC: the column batches of four, one wave per column (k_spmm_ilv8c)
+    uint32_t const* orderP; uint32_t nWGp;   // k_spmm_ilv16p: one wave per chunk, work group b takes the chunks orderP[4 b .. 4 b + 3] (~0: none); nWGp work groups
     uint32_t plainPer;                 // plain mode of k_spmm_mfma, not 0: XCD x (work groups x, x + 8, ...) takes the chunks [x * plainPer, (x + 1) * plainPer)
 };
 
@@ -866,6 +868,193 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 16 x 16 complex<double>, row pairs interleaved, ONE WAVE PER CHUNK with a software pipeline across the chunk's Y blocks (r04).
+// k_spmm_ilv16 gives every Y block a wave of its own: index chain (launch order -> chunk -> pair range -> pairs), operands, block
+// products, epilogue operands, epilogue, stores -- six dependent memory latencies in a row per wave, the HBM-latency epilogue
+// operands in flight for one of them, and only the other two waves of the SIMD to fill the gaps.  Here a wave owns a whole chunk
+// (its <= 4 Y blocks one after the other, their pair ranges are one contiguous piece of the pair list) and runs ONE flat stream of
+// block products over it with the operands of the next two products always in flight (index clamped at the end of the chunk: no
+// conditional load, so the compiler's waits are exact counts); where the stream crosses into the next Y block the wave runs the
+// epilogue of the finished one and requests the epilogue operands of the next one, which then have that block's whole product phase
+// to arrive from HBM.  The four waves of a work group are independent (no LDS, no barrier): work group b takes the four chunks
+// orderP[4 b .. 4 b + 3] (tfq_plan.cpp: the same band of block rows in four neighbouring block columns where the columns have one,
+// so that the four waves ask for the same A blocks at about the same time).
+// Sums: a chunk's record is ((s0 + s1) + s2) + s3 with s_i the lane-group sum of Y block i's lanes -- exactly what k_spmm_ilv16's
+// four waves leave in LDS and add in that order, so the two kernels are bit-identical (tests/test_gpu_hash_mode.py).
+template <int EPI, bool HASH, bool FIRST = false, int NSET = 2>   // NSET: operand sets = block products whose operands are in flight
+__global__ __launch_bounds__(256, (NSET > 2) ? 1 : 2) void k_spmm_ilv16p(SpmmArgs a) {
+    if (gate_closed(a)) return;
+    using R = double;
+    constexpr int LN = 16, P = 256, NPL = EpiPlanes<EPI>::N;
+    constexpr bool UPD = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
+    using T4 = d4;
+    int const lane = threadIdx.x & 63;
+    int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int const lr = lane >> 4, lc = lane & 15;
+    using CU32 = __attribute__((address_space(4))) uint32_t const*;
+    CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
+    CU32 const orderP = (CU32)(uintptr_t)a.orderP; CU32 const chunkFirst = (CU32)(uintptr_t)a.chunkFirst; CU32 const rowI = (CU32)(uintptr_t)a.rowI;
+    uint32_t const chunk = orderP[blockIdx.x * 4 + wave];
+    if (chunk == 0xffffffffu) return;                // (the XCD's share of the order is not a multiple of four chunks)
+    uint32_t const first = chunkFirst[chunk], last = chunkFirst[chunk + 1], col = a.chunkCol[chunk];
+    R sr = 0, si = 0;
+    if constexpr (UPD) { sr = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + lc]; si = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + lc]; }
+    uint32_t const ocol = HASH ? uint32_t(a.origCol[col]) : 0;
+
+    struct Ops { d2v ar[2], ai[2], xr[2], xi[2]; };   // [k pair lr | lr + 4]
+    R const* const A0 = (R const*)a.A + (lr * 16 + ilv_rowp(lc)) * 2;
+    R const* const X0 = (R const*)a.X + (lr * 16 + lc) * 2;
+    auto fetch = [&](Ops& o, uint32_t q) __attribute__((always_inline)) {
+        R const* Ab = A0 + size_t(pairs[2 * size_t(q)]) * 2 * P;
+        R const* Xb = X0 + size_t(pairs[2 * size_t(q) + 1]) * 2 * P;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            o.ar[h] = *(d2v const*)(Ab + h * 128); o.ai[h] = *(d2v const*)(Ab + P + h * 128);
+            o.xr[h] = *(d2v const*)(Xb + h * 128); o.xi[h] = *(d2v const*)(Xb + P + h * 128);
+        }
+    };
+    T4 cre = T4{0, 0, 0, 0}, cim = T4{0, 0, 0, 0};
+    auto mma = [&](Ops const& o) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                R const nai = -o.ai[h][e];
+                cre = Acc<R>::mma(o.ar[h][e], o.xr[h][e], cre);
+                cim = Acc<R>::mma(o.ar[h][e], o.xi[h][e], cim);
+                cre = Acc<R>::mma(nai, o.xi[h][e], cre);
+                cim = Acc<R>::mma(o.ai[h][e], o.xr[h][e], cim);
+            }
+    };
+    // this lane's elements of a Y block: rows (2 lr, 2 lr + 1) and (2 lr + 8, 2 lr + 9) of column lc
+    int const eb[2] = { (lr * 16 + lc) * 2, ((lr + 4) * 16 + lc) * 2 };
+    d2v ur[2], ui[2], vr[2], vi[2]; f2v wr[2], wi[2];
+    auto eload = [&](uint32_t y) __attribute__((always_inline)) {   // old v4 | v5, v8, v3 of Y block y: touched once, non-temporal
+        if constexpr (UPD) {
+            size_t const yoff = size_t(y) * 2 * P;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if constexpr (EPI == EPI_XPAY_DOT && FIRST) { ur[h] = d2v{0, 0}; ui[h] = d2v{0, 0}; vr[h] = d2v{0, 0}; vi[h] = d2v{0, 0}; }   // first iteration: old v4 = v8 = 0, not read
+                else {
+                    ur[h] = ld_stream<true>((d2v const*)((R const*)a.e0 + yoff + eb[h])); ui[h] = ld_stream<true>((d2v const*)((R const*)a.e0 + yoff + eb[h] + P));
+                    if constexpr (EPI == EPI_XPAY_DOT) { vr[h] = ld_stream<true>((d2v const*)((R const*)a.e1 + yoff + eb[h])); vi[h] = ld_stream<true>((d2v const*)((R const*)a.e1 + yoff + eb[h] + P)); }
+                }
+                if constexpr (!HASH) { wr[h] = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff + eb[h])); wi[h] = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff + eb[h] + P)); }
+            }
+        }
+    };
+    double total[NPL > 0 ? NPL : 1] = {};
+    auto epilogue_of = [&](uint32_t y) __attribute__((always_inline)) {   // consumes cre | cim (and clears them) and the epilogue operands
+        double part[NPL > 0 ? NPL : 1] = {};
+        uint64_t const key = HASH ? shadow_key(ocol, rowI[y]) : 0;
+        size_t const yoff = size_t(y) * 2 * P;
+        uint32_t bq = 0xffffffffu;
+        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX ? a.bOfX[y] : y;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint64_t const hqh = HASH ? shadow_quad(key, uint32_t(lr + 4 * h), uint32_t(lc), LN) : 0;
+            d2v yr, yi, nr, ni;
+            d2v br = d2v{0, 0}, bi = d2v{0, 0};
+            if constexpr (EPI == EPI_RESIDUAL) if (bq != 0xffffffffu) {
+                R const* b = (R const*)a.B + size_t(bq) * 2 * P;
+                br = *(d2v const*)(b + eb[h]); bi = *(d2v const*)(b + eb[h] + P);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                yr[e] = cre[2 * h + e]; yi[e] = cim[2 * h + e];
+                // (the same explicit fused multiply-adds as k_spmm_ilv16: the two kernels round alike)
+                if constexpr (EPI == EPI_XPAY_DOT) {         // v9 := A v6; v4 := v8 + beta v4; v4 := v9 + beta v4 (tfqmrgpu_core.hxx:196-202)
+                    R const tr = __builtin_fma(-si, ui[h][e], __builtin_fma(sr, ur[h][e], vr[h][e]));
+                    R const ti = __builtin_fma(sr, ui[h][e], __builtin_fma(si, ur[h][e], vi[h][e]));
+                    nr[e] = __builtin_fma(-si, ti, __builtin_fma(sr, tr, yr[e]));
+                    ni[e] = __builtin_fma(sr, ti, __builtin_fma(si, tr, yi[e]));
+                } else if constexpr (EPI == EPI_AXPY_NRM_DOT) { // v8 := A v6; v5 := alfa v8 + v5 (tfqmrgpu_core.hxx:224-228)
+                    nr[e] = __builtin_fma(-si, yi[e], __builtin_fma(sr, yr[e], ur[h][e]));
+                    ni[e] = __builtin_fma(sr, yi[e], __builtin_fma(si, yr[e], ui[h][e]));
+                }
+                if constexpr (UPD) {
+                    double w0, w1;
+                    if constexpr (HASH) { w0 = shadow_pick(hqh, e, 0); w1 = shadow_pick(hqh, e, 1); }
+                    else { w0 = wr[h][e]; w1 = wi[h][e]; }
+                    double const dr = nr[e], di = ni[e];
+                    part[0] = __builtin_fma(-di, w1, __builtin_fma(dr, w0, part[0]));
+                    part[1] = __builtin_fma(di, w0, __builtin_fma(dr, w1, part[1]));
+                    if constexpr (EPI == EPI_AXPY_NRM_DOT) part[2] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[2]));
+                } else if constexpr (EPI == EPI_RESIDUAL) {     // |A x - b|^2, nothing stored (tfqmrgpu_core.hxx:265-269)
+                    R const rr = yr[e] + R(-1) * br[e], ri = yi[e] + R(-1) * bi[e];
+                    double const dr = rr, di = ri;
+                    part[0] += dr * dr + di * di;
+                }
+            }
+            if constexpr (EPI != EPI_RESIDUAL) {
+                st_stream<true>((d2v*)((R*)a.Y + yoff + eb[h]), yr); st_stream<true>((d2v*)((R*)a.Y + yoff + eb[h] + P), yi);
+            }
+            if constexpr (UPD) {
+                st_stream<true>((d2v*)((R*)a.e0 + yoff + eb[h]), nr); st_stream<true>((d2v*)((R*)a.e0 + yoff + eb[h] + P), ni);
+            }
+        }
+        cre = T4{0, 0, 0, 0}; cim = T4{0, 0, 0, 0};
+        if constexpr (NPL > 0) {
+            bool const firstBlock = (y == first);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {   // rows live on lane / 16 (and registers): add the four lane groups; then the blocks in order
+                double v = part[p];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                total[p] = firstBlock ? v : total[p] + v;
+            }
+        }
+    };
+
+    uint32_t const Q0 = starts[first], Q1 = starts[last];
+    uint32_t const qmax = (Q1 > Q0) ? Q1 - 1 : Q0;   // (a chunk without any product never fetches: see below)
+    uint32_t q = Q0, y = first, qend = starts[first + 1];
+    Ops o[NSET];
+    if (Q1 > Q0) {   // (a chunk without any product never fetches and never multiplies)
+#pragma unroll
+        for (int i = 0; i < NSET; ++i) fetch(o[i], min(Q0 + i, qmax));
+    }
+    eload(y);
+    // A Y block boundary in front of product q: the finished block's epilogue, the next block's epilogue operands requested.  Only called
+    // with q < Q1, so a later block with products exists and y stays below `last`.  A block WITHOUT products behind the boundary (rare)
+    // is handled in a loop of its own: there the epilogue follows its operands' request at once, and if that path ran through the
+    // common epilogue the compiler would have to drain the whole queue -- the operand prefetches too -- in front of every epilogue.
+    auto boundary = [&]() __attribute__((always_inline)) {
+        if (q == qend) {
+            epilogue_of(y); ++y; qend = starts[y + 1]; eload(y);
+            while (__builtin_expect(q == qend, 0)) { epilogue_of(y); ++y; qend = starts[y + 1]; eload(y); }
+        }
+    };
+    // The stream of block products, NSET per trip, a counted loop without an exit inside (a `break` behind a product merges with the
+    // back edge in the structured control flow, and the wait in front of the next trip's first product becomes vmcnt(0)).  The last
+    // trip skips the products behind the end of the stream; the fetches are unconditional (index clamped), so every path issues the
+    // same number of loads and the waits in front of the products are exact counts.
+    uint32_t const trips = (Q1 - Q0 + NSET - 1) / NSET;
+    for (uint32_t t = 0; t < trips; ++t) {
+#pragma unroll
+        for (int i = 0; i < NSET; ++i) {
+            if (i == 0 || q < Q1) { boundary(); mma(o[i]); }
+            fetch(o[i], min(q + NSET, qmax)); ++q;
+        }
+    }
+    // the chunk's last Y block with products, and Y blocks without products behind it
+    for (;;) {
+        epilogue_of(y);
+        if (++y == last) break;
+        eload(y);
+    }
+    if constexpr (NPL > 0) {
+        // (k_spmm_ilv16 adds a zero for every wave without a Y block: the same additions, so that even the sign of a zero sum agrees)
+        for (uint32_t u = last - first; u < 4; ++u)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) total[p] += 0.0;
+        if (lane < 16)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) write_record<EPI>(a, chunk, LN, p, lane, total[p]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 16 x 16 complex<float> with groups of FOUR rows interleaved (plane[r/4][s][r%4]): the float counterpart of k_spmm_ilv16.
 // A lane of v_mfma_f32_16x16x4_f32 loads the k quad lr = lane / 16 (k = 4 lr .. 4 lr + 3) of its column as ONE 16-byte access --
 // MFMA step e contracts k = 4 lr + e -- and its four accumulator registers are the rows 4 lr .. 4 lr + 3 of column lane % 16
@@ -1513,6 +1702,146 @@ __global__ __launch_bounds__(256, 3) void k_spmm_ilv8b(SpmmArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------
+// 8 x 8 complex<double>, column batches of FOUR at WORK-GROUP level (r04): one WAVE per block column.  The work group of chunk c of the first
+// column of a batch (Plan::colBatch, batch size 4; DevPlan::orderC) does chunk c of all four columns, wave w the whole chunk of column w -- the
+// registers, per-column scalars and sums of k_spmm_ilv8, one column per wave -- and the four waves walk down the same block rows together,
+// so that they ask for the same A block within a few hundred cycles of each other: one fetch from the L2, three hits in the CU's L1
+// (k_spmm_ilv8b keeps all columns of a batch in ONE wave, which stops paying beyond two columns: registers).
+// Sums: k_spmm_ilv8 gives wave s the Y blocks s, s + 4, s + 8, ... of a chunk and adds the four waves' sums in order; here the one
+// wave of a column keeps four sets of partial sums, set u % 4 for Y block u: the same additions in the same order, bit-identical records.
+template <int EPI, bool HASH, bool FIRST = false>   // FIRST: the launch of the first iteration of a solve (SpmmArgs::first)
+__global__ __launch_bounds__(256) void k_spmm_ilv8c(SpmmArgs a) {
+    if (gate_closed(a)) return;
+    using R = double;
+    constexpr int LN = 8, P = 64, NPL = EpiPlanes<EPI>::N;
+    constexpr bool UPD = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
+    using T4 = d4;
+    int const lane = threadIdx.x & 63;
+    int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int const lr = lane >> 4, lc = lane & 15, cp = lc >> 3, j = lc & 7;
+    using CU32 = __attribute__((address_space(4))) uint32_t const*;
+    CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
+    uint32_t const lead = a.order[blockIdx.x];                         // a chunk of the batch's first column
+    uint32_t const first = a.chunkFirst[lead], last = a.chunkFirst[lead + 1], col0 = a.chunkCol[lead];
+    uint32_t const col = col0 + uint32_t(wave);                        // this wave's block column (the batch has four)
+    uint32_t const dBlk = a.colStart[col] - a.colStart[col0], chunk = lead + (a.colChunkPtr[col] - a.colChunkPtr[col0]);
+    R sr = 0, si = 0;
+    if constexpr (UPD) { sr = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + j]; si = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + j]; }
+    uint32_t const ocol = HASH ? uint32_t(a.origCol[col]) : 0;
+    double part[4][NPL > 0 ? NPL : 1] = {};
+
+    int const mine = cp * P + (lr * 8 + j) * 2;                                 // this lane's 16 bytes of an X-shaped block
+    R const* const A0 = (R const*)a.A + cp * P + (lr * 8 + 2 * (j & 3) + (j >> 2)) * 2;   // A: row pi(j) of plane cp, k pair lr
+    R const* const X0 = (R const*)a.X + size_t(dBlk) * 2 * P + mine;           // (the column's blocks lie dBlk behind the first column's)
+    struct Ops { d2v av, xv; };
+    auto fetch = [&](Ops& o, uint32_t q) __attribute__((always_inline)) {
+        o.av = *(d2v const*)(A0 + size_t(pairs[2 * size_t(q)]) * 2 * P);
+        o.xv = *(d2v const*)(X0 + size_t(pairs[2 * size_t(q) + 1]) * 2 * P);
+    };
+    uint32_t const nblk = last - first;
+    for (uint32_t u0 = 0; u0 < nblk; u0 += 4) {
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {
+            if (u0 + sl < nblk) {
+            uint32_t const y0 = first + u0 + sl;               // the first column's Y block: its pair list and block row are the batch's
+            uint64_t const key = HASH ? shadow_key(ocol, a.rowI[y0]) : 0;
+            T4 acc = T4{0, 0, 0, 0};
+            uint32_t const q0 = starts[y0], nq = starts[y0 + 1] - q0;
+            constexpr int DEPTH = 4;
+            Ops o[DEPTH];
+            size_t const yoff = size_t(y0 + dBlk) * 2 * P + mine;
+            d2v uM = d2v{0, 0}, vM = d2v{0, 0}; f2v wM = f2v{0, 0};
+            if constexpr (UPD) {                       // the epilogue operands travel while the products are computed
+                if constexpr (!(EPI == EPI_XPAY_DOT && FIRST)) {   // (first iteration of a solve: old v4 = v8 = 0, not read)
+                    uM = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff));
+                    if constexpr (EPI == EPI_XPAY_DOT) vM = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff));
+                }
+                if constexpr (!HASH) wM = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff));
+            }
+#pragma unroll
+            for (int dd = 0; dd < DEPTH; ++dd) if (uint32_t(dd) < nq) fetch(o[dd], q0 + dd);
+            for (uint32_t base = 0; base < nq; base += DEPTH) {
+#pragma unroll
+                for (int dd = 0; dd < DEPTH; ++dd) {
+                    if (base + dd < nq) {
+                        acc = Acc<R>::mma(o[dd].av[0], o[dd].xv[0], acc);
+                        acc = Acc<R>::mma(o[dd].av[1], o[dd].xv[1], acc);
+                        if (base + dd + DEPTH < nq) fetch(o[dd], q0 + base + dd + DEPTH);
+                    }
+                }
+            }
+            // lanes of plane 0 hold (Q00, Q10), lanes of plane 1 (Q01, Q11), rows 2 lr and 2 lr + 1: Re Y = Q00 - Q11, Im Y = Q01 + Q10
+            d2v const qa = d2v{acc[0], acc[1]}, qb = xor8(d2v{acc[2], acc[3]});
+            d2v const yM = cp ? d2v{qa[0] + qb[0], qa[1] + qb[1]} : d2v{qa[0] - qb[0], qa[1] - qb[1]};   // this lane's plane of Y
+            d2v const yO = xor8(yM);
+            d2v const yr = cp ? yO : yM, yi = cp ? yM : yO;
+            if constexpr (UPD) {
+                d2v const uO = xor8(uM), ur = cp ? uO : uM, ui = cp ? uM : uO;
+                d2v nr, ni;
+                d2v w0, w1;     // the shadow vector: Re and Im of the two elements
+                if constexpr (HASH) {
+                    uint64_t const hq = shadow_quad(key, uint32_t(lr), uint32_t(j), LN);   // rows 2 lr, 2 lr + 1 of column j
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) { w0[e] = shadow_pick(hq, e, 0); w1[e] = shadow_pick(hq, e, 1); }
+                } else {
+                    f2v const wO = f2v{__shfl_xor(wM[0], 8), __shfl_xor(wM[1], 8)};
+                    w0 = cp ? d2v{wO[0], wO[1]} : d2v{wM[0], wM[1]}; w1 = cp ? d2v{wM[0], wM[1]} : d2v{wO[0], wO[1]};
+                }
+                if constexpr (EPI == EPI_XPAY_DOT) {          // v9 := A v6; v4 := v8 + beta v4; v4 := v9 + beta v4 (tfqmrgpu_core.hxx:196-202)
+                    d2v const vO = xor8(vM), vr = cp ? vO : vM, vi = cp ? vM : vO;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        R const tr = __builtin_fma(-si, ui[e], __builtin_fma(sr, ur[e], vr[e]));
+                        R const ti = __builtin_fma(sr, ui[e], __builtin_fma(si, ur[e], vi[e]));
+                        nr[e] = __builtin_fma(-si, ti, __builtin_fma(sr, tr, yr[e]));
+                        ni[e] = __builtin_fma(sr, ti, __builtin_fma(si, tr, yi[e]));
+                    }
+                } else {                                      // v8 := A v6; v5 := alfa v8 + v5 (tfqmrgpu_core.hxx:224-228)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        nr[e] = __builtin_fma(-si, yi[e], __builtin_fma(sr, yr[e], ur[e]));
+                        ni[e] = __builtin_fma(sr, yi[e], __builtin_fma(si, yr[e], ui[e]));
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {                 // every lane has both parts: the lanes of plane 0 are the ones that count
+                    double const dr = nr[e], di = ni[e];
+                    part[sl][0] = __builtin_fma(-di, w1[e], __builtin_fma(dr, w0[e], part[sl][0]));
+                    part[sl][1] = __builtin_fma(di, w0[e], __builtin_fma(dr, w1[e], part[sl][1]));
+                    if constexpr (EPI == EPI_AXPY_NRM_DOT) part[sl][2] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[sl][2]));
+                }
+                __builtin_nontemporal_store(yM, (d2v*)((R*)a.Y + yoff));
+                __builtin_nontemporal_store(cp ? ni : nr, (d2v*)((R*)a.e0 + yoff));
+            } else if constexpr (EPI == EPI_RESIDUAL) {       // |A x - b|^2, nothing stored (tfqmrgpu_core.hxx:265-269)
+                uint32_t const bq = a.bOfX ? a.bOfX[y0 + dBlk] : y0 + dBlk;
+                d2v bM = d2v{0, 0};
+                if (bq != 0xffffffffu) bM = *(d2v const*)((R const*)a.B + size_t(bq) * 2 * P + mine);
+                d2v const bO = xor8(bM), br = cp ? bO : bM, bi = cp ? bM : bO;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    double const dr = yr[e] + R(-1) * br[e], di = yi[e] + R(-1) * bi[e];
+                    part[sl][0] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[sl][0]));
+                }
+            } else {
+                __builtin_nontemporal_store(yM, (d2v*)((R*)a.Y + yoff));
+            }
+            }
+        }
+    }
+    if constexpr (NPL > 0) {
+        // the rows of a column sit 16 lanes apart (lr); lanes 0..7 (plane 0, lr 0) hold the column sums: the four sets in k_spmm_ilv8's order of waves
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+            double v[4];
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) { v[sl] = part[sl][p]; v[sl] += __shfl_xor(v[sl], 16); v[sl] += __shfl_xor(v[sl], 32); }
+            double const sum = ((v[0] + v[1]) + v[2]) + v[3];
+            if (lane < 8) write_record<EPI>(a, chunk, LN, p, lane, sum);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // 8 x 32 and 8 x 64 complex<double> on the row-pair-interleaved order: k_spmm_ilv8's tile ([Re A; Im A] x [Re X | Im X], one exchange
 // with the lane 8 further) once per group of 8 block columns.  A wave-wide 16-byte access covers both planes and all 8 rows of ONE
 // column group (8 segments of 128 bytes), so a block product is 1 + LN / 8 loads of 1 KiB (k_spmm_mfma8 on the native order: 2 + 2 LN / 8
@@ -2087,6 +2416,18 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
             bool const hash = canHashI && a.hashV3;
             // (the first-iteration launch of EPI_XPAY_DOT is its own instance: a test of the flag per Y block costs the steady launches 0.5 %)
             constexpr bool canFirst = (EPI == EPI_XPAY_DOT);
+            if (a.orderP && !a.aOnce && !a.foldPlan) {   // one wave per chunk, pipelined across its Y blocks (tfq_plan.cpp: orderP; large plans)
+                dim3 const g(a.nWGp);
+                static size_t const padP = size_t(lab_switch("TFQMRGPU_PIPE_LDS_KIB", 0)) << 10;   // (lab: unused dynamic LDS limits the work groups per CU)
+                static int const nset = lab_switch("TFQMRGPU_PIPE_NSET", 2);
+                auto goP = [&](auto N) {
+                    constexpr int NS = decltype(N)::value;
+                    if (canFirst && a.first) { if (hash) k_spmm_ilv16p<EPI, canHashI, canFirst, NS><<<g, dim3(256), padP, s>>>(a); else k_spmm_ilv16p<EPI, false, canFirst, NS><<<g, dim3(256), padP, s>>>(a); }
+                    else { if (hash) k_spmm_ilv16p<EPI, canHashI, false, NS><<<g, dim3(256), padP, s>>>(a); else k_spmm_ilv16p<EPI, false, false, NS><<<g, dim3(256), padP, s>>>(a); }
+                };
+                if (4 == nset) goP(std::integral_constant<int, 4>{}); else if (3 == nset) goP(std::integral_constant<int, 3>{}); else goP(std::integral_constant<int, 2>{});
+                return;
+            }
             if (canFirst && a.first) {
                 if (a.aOnce) { if (hash) k_spmm_ilv16<EPI, canHashI, true, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16<EPI, false, true, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a); }
                 else         { if (hash) k_spmm_ilv16<EPI, canHashI, false, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_ilv16<EPI, false, false, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a); }
@@ -2128,6 +2469,16 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
         if (a.ilv && a.chunkFirst) {
             constexpr bool canHash8 = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
             constexpr bool canFirst = (EPI == EPI_XPAY_DOT);
+            if (a.colBatch && a.wide) {   // batches of four block columns with identical row patterns, one wave per column (tfq_plan.cpp: colBatch, orderC)
+                if (canFirst && a.first) {
+                    if (canHash8 && a.hashV3) k_spmm_ilv8c<EPI, canHash8, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a);
+                    else k_spmm_ilv8c<EPI, false, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a);
+                    return;
+                }
+                if (canHash8 && a.hashV3) k_spmm_ilv8c<EPI, canHash8><<<dim3(nWG), dim3(256), 0, s>>>(a);
+                else k_spmm_ilv8c<EPI, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
+                return;
+            }
             if (a.colBatch) {   // block columns with identical row patterns, multiplied kColBatchMax at a time (tfq_plan.cpp: colBatch; the launch runs over the first columns' chunks)
                 constexpr int NBATCH = kColBatchMax;
                 if (canFirst && a.first) {
@@ -2255,6 +2606,7 @@ static SpmmArgs spmm_args(int epi, DevPlan const& d) {
     a.foldPlan = d.fold ? d.self : nullptr;
     a.hashV3 = d.hashV3; a.origCol = d.origCol; a.rowI = d.rowI; a.ilv = d.ilv; a.aOnce = d.aOnce;
     a.colBatch = d.colBatch; a.colStart = d.colStart; a.colChunkPtr = d.colChunkPtr;
+    a.orderP = d.orderP; a.nWGp = d.nWGp;
     switch (epi) {
     case EPI_XPAY_DOT:     a.X = d.v6; a.Y = d.v9; a.e0 = d.v4; a.e1 = d.v8; a.sc = d.beta; a.gate = 1; a.first = d.first; break;
     case EPI_AXPY_NRM_DOT: a.X = d.v6; a.Y = d.v8; a.e0 = d.v5; a.sc = d.alfa; a.gate = 1; break;
@@ -2272,6 +2624,7 @@ void spmm_launch(int epi, DevPlan const& d, hipStream_t s) {
     SpmmArgs a = spmm_args(epi, d);
     if (batched(d)) a.order = d.orderB; else a.colBatch = nullptr;
     spmm_dispatch(d.dbl, d.LM, d.LN, epi, a, batched(d) ? d.nChunksB : d.nChunks, s);
+    if (batched(d) && d.nChunksC) { a.order = d.orderC; a.wide = 1; spmm_dispatch(d.dbl, d.LM, d.LN, epi, a, d.nChunksC, s); }   // the batches of four: a launch of their own
 }
 
 // Y = A * X on vectors of the plan (both in the plan's own block and element order), no epilogue, never gated
@@ -2280,6 +2633,7 @@ void spmm_apply(DevPlan const& d, void const* X, void* Y, hipStream_t s) {
     a.X = X; a.Y = Y; a.gate = 0;
     if (batched(d)) a.order = d.orderB; else a.colBatch = nullptr;
     spmm_dispatch(d.dbl, d.LM, d.LN, EPI_NONE, a, batched(d) ? d.nChunksB : d.nChunks, s);
+    if (batched(d) && d.nChunksC) { a.order = d.orderC; a.wide = 1; spmm_dispatch(d.dbl, d.LM, d.LN, EPI_NONE, a, d.nChunksC, s); }
 }
 
 template <typename R, int LM, int LN>

@@ -99,6 +99,27 @@ template <typename R> __device__ inline void axpy(R& yr, R& yi, R xr, R xi, R ar
 
 // Sum the per-thread accumulators of a work group into out[NPL][LN] (one record per chunk).
 // Fixed order => bitwise reproducible.  s is LDS of NPL*256*VEC doubles.
+// The terms of one sum, in order: element m of the work group's slice belongs to column (m / G) % LN for plans that keep G rows of a
+// column together (ILV = G, tfq_device.hpp: ilv_offset), to column m % LN otherwise.  (r04) ILV is a template parameter and the
+// terms are fetched in batches of 16 before they are added: with the run-time `ilv` of r01-r03 every LDS read waited for the
+// addition in front of it -- 32 dependent round trips by 16 threads at the end of every work group of k_v5_nrm, which is what made
+// that kernel stream at 5.8 TB/s where k_xpay_v6, the same three vectors without a sum, reaches 6.6.  Same additions, same order.
+template <int LN, int VEC, int T, int ILV>
+__device__ inline double ordered_sum(double const* sp, int j) {
+    constexpr int terms = (T * VEC) / LN, B = (terms < 16) ? terms : 16, full = terms / B * B;
+    auto at = [&](int n) { return ILV ? sp[((n / ILV) * LN + j) * ILV + n % ILV] : sp[n * LN + j]; };
+    double sum = 0;
+    for (int n0 = 0; n0 < full; n0 += B) {
+        double v[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) v[i] = at(n0 + i);
+#pragma unroll
+        for (int i = 0; i < B; ++i) sum += v[i];
+    }
+#pragma unroll
+    for (int n = full; n < terms; ++n) sum += at(n);
+    return sum;
+}
 template <int LN, int VEC, int T, int NPL>
 __device__ inline void chunk_reduce(double (&acc)[NPL][VEC], double* s, double* out, int t, int ilv = 0) {
     __syncthreads();
@@ -109,16 +130,10 @@ __device__ inline void chunk_reduce(double (&acc)[NPL][VEC], double* s, double* 
             for (int v = 0; v < VEC; ++v) s[p * (256 * VEC) + t * VEC + v] = acc[p][v];
     }
     __syncthreads();
-    constexpr int terms = (T * VEC) / LN;
     for (int e = t; e < NPL * LN; e += 256) {
         int const p = e / LN, j = e % LN;
-        double sum = 0;
-        if (ilv) {   // element m of the work group's slice belongs to column (m / G) % LN: G rows, then the next column
-            for (int n = 0; n < terms / ilv; ++n)
-                for (int g = 0; g < ilv; ++g) sum += s[p * (256 * VEC) + (n * LN + j) * ilv + g];
-        } else
-        for (int n = 0; n < terms; ++n) sum += s[p * (256 * VEC) + n * LN + j];
-        out[p * LN + j] = sum;
+        double const* sp = s + p * (256 * VEC);
+        out[p * LN + j] = (2 == ilv) ? ordered_sum<LN, VEC, T, 2>(sp, j) : (4 == ilv) ? ordered_sum<LN, VEC, T, 4>(sp, j) : ordered_sum<LN, VEC, T, 0>(sp, j);
     }
 }
 
