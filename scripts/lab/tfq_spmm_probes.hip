@@ -37,8 +37,38 @@
 #include "tfq_switch.hpp"
 #include "tfq_colops.hpp"
 
-// (timing-only variants of the kernels below -- block products or fetches skipped, stamps, the shader clock under load: results wrong by
-//  construction -- live in a copy of their own, scripts/lab/tfq_spmm_probes.hip, built with scripts/build_variant.sh; nothing of them is in this file)
+#ifdef TFQ_LAB_CLOCK
+// builds with -DTFQ_LAB_CLOCK only (scripts/build_variant.sh clock -DTFQ_LAB -DTFQ_LAB_CLOCK; the two clock reads cost k_spmm_ilv16 7 %, so
+// not even the regular lab build carries them): shader clock under the real kernel's load.  k_spmm_ilv16 adds, per work group, its lifetime in shader clocks
+// (s_memtime) and in the constant 100 MHz clock (s_memrealtime) to three counters {clocks, ticks, work groups} the caller points to
+// with tfqmrgpuLab_clockRecord (nullptr: off); average frequency = clocks / ticks * 100 MHz (scripts/clock_under_load.py;
+// r03: 2.36-2.38 GHz during a solve -- no throttling under matrix + HBM load, profiles/r03_ab_desc_clock.txt).
+__device__ unsigned long long* g_tfqClockRec = nullptr;
+extern "C" int tfqmrgpuLab_clockRecord(unsigned long long* threeCountersOnTheDevice) {
+    return int(hipMemcpyToSymbol(HIP_SYMBOL(g_tfqClockRec), &threeCountersOnTheDevice, sizeof threeCountersOnTheDevice));
+}
+#endif
+
+#ifdef TFQ_LAB_STAMPS
+// builds with -DTFQ_LAB_STAMPS only (scripts/build_variant.sh stamps -DTFQ_LAB -DTFQ_LAB_STAMPS): a timeline of ONE wave per work group of k_spmm_ilv16 in the constant
+// 100 MHz clock (s_memrealtime): [work group][8] = entry | state known | chunk known | pair range known | first operands + epilogue operands landed | products done |
+// stores issued | records written.  The waits in front of the stamps are part of the variant: it is a diagnostic of latency-bound (small) launches, scripts/wg_timeline.py.
+__device__ unsigned long long* g_tfqStamps = nullptr;
+__device__ int g_tfqStampEpi = 0;           // which instance stamps: the epilogue number (0: the plain multiply)
+extern "C" int tfqmrgpuLab_stamps(unsigned long long* eightPerWorkGroupOnTheDevice, int epilogue) {
+    if (hipSuccess != hipMemcpyToSymbol(HIP_SYMBOL(g_tfqStampEpi), &epilogue, sizeof epilogue)) return 1;
+    return int(hipMemcpyToSymbol(HIP_SYMBOL(g_tfqStamps), &eightPerWorkGroupOnTheDevice, sizeof eightPerWorkGroupOnTheDevice));
+}
+#define TFQ_KEEP2(a, b) asm volatile("" :: "s"(a), "s"(b))
+// (work groups that the gate turns away do not stamp: every launch of the chosen instance that does work overwrites the one before, the last one stays)
+#define TFQ_STAMP_ENTRY unsigned long long const stampEntry_ = wall_clock64();
+#define TFQ_STAMP(k, waits) do { asm volatile(waits ::: "memory"); if (g_tfqStamps && g_tfqStampEpi == EPI && 0 == threadIdx.x) { \
+    if (1 == (k)) g_tfqStamps[size_t(blockIdx.x) * 8] = stampEntry_; g_tfqStamps[size_t(blockIdx.x) * 8 + (k)] = wall_clock64(); } } while (0)
+#else
+#define TFQ_KEEP2(a, b) do {} while (0)
+#define TFQ_STAMP_ENTRY
+#define TFQ_STAMP(k, waits) do {} while (0)
+#endif
 
 namespace tfq {
 
@@ -644,9 +674,21 @@ using f2v = __attribute__((ext_vector_type(2))) float;
 // once per multiply -- the kernel is a stream of A through HBM, and 16-byte non-temporal loads take it from 5.5 to 6.6 TB/s
 // (one block column, 1.3 GB of A: plain multiply 0.69 -> 0.82 of 8 TB/s, fused 0.76 -> 0.85, profiles/r02_lab.txt); with
 // many columns A is re-used out of the caches and must stay there (the plan decides: SpmmArgs::aOnce).
+// TFQ_PROBE (timing-only variants for scripts/build_variant.sh, results WRONG; never set in a build that ships): bit 0: no block products,
+// 1: chunks in linear order, 2: plain instead of non-temporal epilogue accesses, 3: no record reduction, 4: Y not stored, 5: shadow vector = 1
+#ifndef TFQ_PROBE
+#define TFQ_PROBE 0
+#endif
+// ELDS (lab): the epilogue operands (old v4 | v5, v8) land in LDS by LDS-DMA instead of in 16 | 32 VGPRs, which brings the fused
+// instances under 128 VGPRs = four waves per SIMD (4 | 8 KiB of LDS per wave)
 template <int EPI, bool HASH, bool ANT = false, bool FIRST = false>   // FIRST: the launch of the first iteration of a solve (SpmmArgs::first)
 __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
+#ifdef TFQ_LAB_CLOCK
+    long long const labC0 = clock64(), labW0 = wall_clock64();
+#endif
+    TFQ_STAMP_ENTRY
     if (gate_closed(a)) return;
+    TFQ_STAMP(1, "s_waitcnt lgkmcnt(0)");
     using R = double;
     constexpr int LN = 16, P = 256, NPL = EpiPlanes<EPI>::N;
     constexpr bool UPD = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
@@ -657,8 +699,10 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
     // the index lists through the constant address space: uniform reads become scalar loads whatever the stores around them
     using CU32 = __attribute__((address_space(4))) uint32_t const*;
     CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
-    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;   // XCD-aware launch order (tfq_plan.cpp)
+    uint32_t const chunk = (a.order && !(TFQ_PROBE & 2)) ? a.order[blockIdx.x] : blockIdx.x;   // XCD-aware launch order (tfq_plan.cpp)
     uint32_t const first = a.chunkFirst[chunk], last = a.chunkFirst[chunk + 1], col = a.chunkCol[chunk];
+    TFQ_KEEP2(first, last); TFQ_KEEP2(col, col);
+    TFQ_STAMP(2, "s_waitcnt lgkmcnt(0)");
     R sr = 0, si = 0;
     if constexpr (UPD) { sr = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + lc]; si = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + lc]; }
     double part[NPL > 0 ? NPL : 1] = {};
@@ -670,11 +714,14 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
     auto fetch = [&](Ops& o, uint32_t q) __attribute__((always_inline)) {
         R const* Ab = A0 + size_t(pairs[2 * size_t(q)]) * 2 * P;
         R const* Xb = X0 + size_t(pairs[2 * size_t(q) + 1]) * 2 * P;
+        bool const ldA = !(TFQ_PROBE & 64) || (q & 6) == 0, ldX = !(TFQ_PROBE & 128) || (q & 6) == 0;   // (probes: 3 of 4 operand fetches skipped, stale registers)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            if (ldA) {
             if constexpr (ANT) { o.ar[h] = __builtin_nontemporal_load((d2v const*)(Ab + h * 128)); o.ai[h] = __builtin_nontemporal_load((d2v const*)(Ab + P + h * 128)); }
             else { o.ar[h] = *(d2v const*)(Ab + h * 128); o.ai[h] = *(d2v const*)(Ab + P + h * 128); }
-            o.xr[h] = *(d2v const*)(Xb + h * 128); o.xi[h] = *(d2v const*)(Xb + P + h * 128);
+            }
+            if (ldX) { o.xr[h] = *(d2v const*)(Xb + h * 128); o.xi[h] = *(d2v const*)(Xb + P + h * 128); }
         }
     };
     for (uint32_t u = wave; u < last - first; u += 4) {
@@ -693,8 +740,13 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
                     cim = Acc<R>::mma(o.ai[h][e], o.xr[h][e], cim);
                 }
         };
-        uint32_t const q0 = starts[y], q1 = starts[y + 1];
+        uint32_t const q0 = starts[y], q1 = (TFQ_PROBE & 1) ? q0 : starts[y + 1];
+        TFQ_KEEP2(q0, q1);
+        TFQ_STAMP(3, "s_waitcnt lgkmcnt(0)");
         Ops o0, o1;
+        if constexpr ((TFQ_PROBE & 192) != 0) {   // (probes: defined contents for the skipped fetches)
+            for (int h = 0; h < 2; ++h) { o0.ar[h] = o0.ai[h] = o0.xr[h] = o0.xi[h] = o1.ar[h] = o1.ai[h] = o1.xr[h] = o1.xi[h] = d2v{1e-3 * lane, 1e-3}; }
+        }
         // the epilogue operands of EPI_AXPY_NRM_DOT (4 loads) are requested in FRONT of the first two block products' operands, those of
         // EPI_XPAY_DOT (8 loads) behind them: measured both ways, profiles/r02_ab_traversal.txt (vmcnt retires in order)
         constexpr bool EPI_FIRST = (EPI == EPI_AXPY_NRM_DOT);
@@ -711,8 +763,8 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
             for (int h = 0; h < 2; ++h) {   // old v4 | v5, v8, v3: touched once, non-temporal
                 if constexpr (EPI == EPI_XPAY_DOT && FIRST) { ur[h] = d2v{0, 0}; ui[h] = d2v{0, 0}; vr[h] = d2v{0, 0}; vi[h] = d2v{0, 0}; }   // first iteration: old v4 = v8 = 0, not read
                 else {
-                ur[h] = ld_stream<true>((d2v const*)((R const*)a.e0 + yoff + eb[h])); ui[h] = ld_stream<true>((d2v const*)((R const*)a.e0 + yoff + eb[h] + P));
-                if constexpr (EPI == EPI_XPAY_DOT) { vr[h] = ld_stream<true>((d2v const*)((R const*)a.e1 + yoff + eb[h])); vi[h] = ld_stream<true>((d2v const*)((R const*)a.e1 + yoff + eb[h] + P)); }
+                ur[h] = ld_stream<!(TFQ_PROBE & 4)>((d2v const*)((R const*)a.e0 + yoff + eb[h])); ui[h] = ld_stream<!(TFQ_PROBE & 4)>((d2v const*)((R const*)a.e0 + yoff + eb[h] + P));
+                if constexpr (EPI == EPI_XPAY_DOT) { vr[h] = ld_stream<!(TFQ_PROBE & 4)>((d2v const*)((R const*)a.e1 + yoff + eb[h])); vi[h] = ld_stream<!(TFQ_PROBE & 4)>((d2v const*)((R const*)a.e1 + yoff + eb[h] + P)); }
                 }
                 if constexpr (!HASH) { wr[h] = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff + eb[h])); wi[h] = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff + eb[h] + P)); }
             }
@@ -724,6 +776,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
         // (r03, profiles/r03_ab_exact_waits.txt: the conditional prefetches make the compiler wait with vmcnt(0) in front of every pair of
         //  products; both forms with exact waits -- prefetch index clamped to the last product, or straight-line tails behind a loop that
         //  always prefetches -- measured 4-8 % SLOWER on P2: redundant cache-hot fetches, or 192 VGPRs = two waves per SIMD)
+        TFQ_STAMP(4, "s_waitcnt vmcnt(0)");
         uint32_t q = q0;
         for (; q + 2 <= q1; q += 2) {
             mma(o0);
@@ -732,6 +785,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
             if (q + 3 < q1) fetch(o1, q + 3);
         }
         if (q < q1) mma(o0);
+        TFQ_STAMP(5, "s_nop 0");
 
         uint32_t bq = 0xffffffffu;
         if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX ? a.bOfX[y] : y;
@@ -739,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
         for (int h = 0; h < 2; ++h) {
             // the shadow vector recomputed: one hash for this pair of rows (tfq_device.hpp: shadow_quad).  Drawn here, inside the loop:
             // both hashes in front of it cost spmm_v4_dot 2 % (0.626 against 0.614 ms on P2, profiles/r02_ab_hash.txt)
-            uint64_t const hqh = HASH ? shadow_quad(key, uint32_t(lr + 4 * h), uint32_t(lc), LN) : 0;
+            uint64_t const hqh = (HASH && !(TFQ_PROBE & 32)) ? shadow_quad(key, uint32_t(lr + 4 * h), uint32_t(lc), LN) : 0;
             d2v yr, yi, nr, ni;
             d2v br = d2v{0, 0}, bi = d2v{0, 0};
             if constexpr (EPI == EPI_RESIDUAL) if (bq != 0xffffffffu) {
@@ -774,15 +828,17 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
                     part[0] += dr * dr + di * di;
                 }
             }
-            if constexpr (EPI != EPI_RESIDUAL) {
-                st_stream<true>((d2v*)((R*)a.Y + yoff + eb[h]), yr); st_stream<true>((d2v*)((R*)a.Y + yoff + eb[h] + P), yi);
+            if constexpr (EPI != EPI_RESIDUAL && !((TFQ_PROBE & 16) && UPD)) {
+                st_stream<!(TFQ_PROBE & 4)>((d2v*)((R*)a.Y + yoff + eb[h]), yr); st_stream<!(TFQ_PROBE & 4)>((d2v*)((R*)a.Y + yoff + eb[h] + P), yi);
             }
             if constexpr (UPD) {
-                st_stream<true>((d2v*)((R*)a.e0 + yoff + eb[h]), nr); st_stream<true>((d2v*)((R*)a.e0 + yoff + eb[h] + P), ni);
+                st_stream<!(TFQ_PROBE & 4)>((d2v*)((R*)a.e0 + yoff + eb[h]), nr); st_stream<!(TFQ_PROBE & 4)>((d2v*)((R*)a.e0 + yoff + eb[h] + P), ni);
             }
         }
     }
-    if constexpr (NPL > 0) {
+    TFQ_STAMP(6, "");
+    if constexpr (NPL > 0 && (TFQ_PROBE & 8)) { if (part[0] == 1.2345e300 && part[1] == 5.4321e300) write_record<EPI>(a, chunk, LN, 0, lane & 15, part[NPL - 1]); }
+    else if constexpr (NPL > 0) {
         // rows live on lane / 16 (and registers): add the four lane groups, then the four waves in order
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
@@ -799,6 +855,14 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16(SpmmArgs a) {
         }
         if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
     }
+    TFQ_STAMP(7, "s_waitcnt vmcnt(0) lgkmcnt(0)");
+#ifdef TFQ_LAB_CLOCK
+    if (g_tfqClockRec && 0 == threadIdx.x) {
+        atomicAdd(g_tfqClockRec, (unsigned long long)(clock64() - labC0));
+        atomicAdd(g_tfqClockRec + 1, (unsigned long long)(wall_clock64() - labW0));
+        atomicAdd(g_tfqClockRec + 2, 1ull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -835,9 +899,11 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
     auto fetch = [&](Ops& o, uint32_t q) __attribute__((always_inline)) {
         R const* Ab = A0 + size_t(pairs[2 * size_t(q)]) * 2 * P;
         R const* Xb = X0 + size_t(pairs[2 * size_t(q) + 1]) * 2 * P;
+        if (!(TFQ_PROBE & 64) || (q & 6) == 0) {   // (probes: 3 of 4 fetches skipped, stale registers)
         if constexpr (ANT) { o.ar = __builtin_nontemporal_load((f4v const*)Ab); o.ai = __builtin_nontemporal_load((f4v const*)(Ab + P)); }
         else { o.ar = *(f4v const*)Ab; o.ai = *(f4v const*)(Ab + P); }
-        o.xr = *(f4v const*)Xb; o.xi = *(f4v const*)(Xb + P);
+        }
+        if (!(TFQ_PROBE & 128) || (q & 6) == 0) { o.xr = *(f4v const*)Xb; o.xi = *(f4v const*)(Xb + P); }
     };
     for (uint32_t u = wave; u < last - first; u += 4) {
         uint32_t const y = first + u;
@@ -855,6 +921,7 @@ __global__ __launch_bounds__(256, 2) void k_spmm_ilv16f(SpmmArgs a) {
         };
         uint32_t const q0 = starts[y], q1 = starts[y + 1];
         Ops o0, o1;
+        if constexpr ((TFQ_PROBE & 192) != 0) { o0.ar = f4v{1e-3f * lane, 1e-3f, 2e-3f, 3e-3f}; o0.ai = o0.ar; o0.xr = o0.ar; o0.xi = o0.ar; o1 = o0; }   // (probes: defined contents)
         constexpr bool EPI_FIRST = true;   // epilogue operands requested in front of the first products' operands: -1 % (profiles/r02_ab_traversal.txt)
         if constexpr (!EPI_FIRST) {
             if (q0 < q1) fetch(o0, q0);
@@ -1164,8 +1231,8 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8(SpmmArgs a) {
     R const* const X0 = (R const*)a.X + mine;
     struct Ops { d2v av, xv; };
     auto fetch = [&](Ops& o, uint32_t q) __attribute__((always_inline)) {
-        o.av = *(d2v const*)(A0 + size_t(pairs[2 * size_t(q)]) * 2 * P);
-        o.xv = *(d2v const*)(X0 + size_t(pairs[2 * size_t(q) + 1]) * 2 * P);
+        if (!(TFQ_PROBE & 64) || (q & 3) == 0) o.av = *(d2v const*)(A0 + size_t(pairs[2 * size_t(q)]) * 2 * P);       // (probes: 3 of 4 fetches skipped, stale registers)
+        if (!(TFQ_PROBE & 128) || (q & 3) == 0) o.xv = *(d2v const*)(X0 + size_t(pairs[2 * size_t(q) + 1]) * 2 * P);
     };
     for (uint32_t u = wave; u < last - first; u += 4) {
         uint32_t const y = first + u;
@@ -1174,6 +1241,7 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8(SpmmArgs a) {
         uint32_t const q0 = starts[y], nq = starts[y + 1] - q0;
         constexpr int DEPTH = 4;
         Ops o[DEPTH];
+        if constexpr ((TFQ_PROBE & 192) != 0) { for (int dd = 0; dd < DEPTH; ++dd) { o[dd].av = d2v{1e-3 * lane, 1e-3}; o[dd].xv = o[dd].av; } }   // (probes: defined contents)
         constexpr bool EPI_FIRST = true;   // epilogue operands requested in front of the first products' operands: -1 % (profiles/r02_ab_traversal.txt)
         if constexpr (!EPI_FIRST) {
 #pragma unroll
@@ -1279,7 +1347,7 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8(SpmmArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // 8 x 8 complex<double>, COLUMN-BATCHED (r03).  Block columns whose row patterns are identical (Plan::colBatch: dense right-hand-side columns, BASELINE
-// config 5) are multiplied nb <= kColBatchMax = 2 at a time: the work group of chunk c of the FIRST column of a batch also does chunk c of the other columns -- same
+// config 5) are multiplied nb <= 4 at a time: the work group of chunk c of the FIRST column of a batch also does chunk c of the other columns -- same
 // block rows, same A blocks, the X / Y blocks a column's block count further on -- so that an A block is fetched once for nb block products; the launch
 // runs over the chunks of the batches' first columns only (DevPlan::orderB).  With blocks of 1 KiB the operand path bounds this shape (timing-only probe, profiles/r03_probes.txt:
 // 3 of 4 A fetches skipped = -16 % / -22 % on the fused multiplies).  Chunks, records and every sum are those of k_spmm_ilv8: bit-identical results.
@@ -1329,7 +1397,10 @@ __global__ __launch_bounds__(256, 3) void k_spmm_ilv8b(SpmmArgs a) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) acc[k] = T4{0, 0, 0, 0};
         uint32_t const q0 = starts[y], nq = starts[y + 1] - q0;
-        constexpr int DEPTH = 2;   // block products in flight (3 | 4 measured level or slower, profiles/r03_column_batches.txt)
+#ifndef TFQ_B8_DEPTH
+#define TFQ_B8_DEPTH 2
+#endif
+        constexpr int DEPTH = TFQ_B8_DEPTH;   // block products in flight (variant builds: 3, 4)
         Ops o[DEPTH];
 #pragma unroll
         for (int dd = 0; dd < DEPTH; ++dd) if (uint32_t(dd) < nq) fetch(o[dd], q0 + dd);

@@ -6,8 +6,11 @@ line by line, T x T tiles, Morton order.  Prints the per-launch times of the two
 usage: python scripts/row_order_probe.py [G list, e.g. 4,8,16] [orders, e.g. natural,strip8]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# TFQMRGPU_ORDER_G is a tuning switch: only the LAB build reads it (the product has its switches frozen since commit ab30726, tfq_switch.hpp)
+os.environ.setdefault("TFQMRGPU_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tfqmrgpu_amd", "lib", "libtfQMRgpu_lab.so"))
 import numpy as np
 import tfqmrgpu_amd as T_
+assert "lab" in os.path.basename(T_.LIB_PATH), "the column-group sweep needs the lab build: " + T_.LIB_PATH
 from tfqmrgpu_amd.fd_generator import FDExample
 
 

@@ -73,5 +73,9 @@ j)
   step 900 r04j_bits.txt python scripts/pipe_bits.py
   cat gpurun_out/r04j_bits.txt
   ;;
+k)
+  # the product without the probe hooks, run_mixed's failure protocol, the fenced fold: the whole GPU suite
+  step 1100 r04k_tests.log python -m pytest tests -q -x -m gpu
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac

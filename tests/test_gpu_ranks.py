@@ -59,3 +59,21 @@ def test_a_failing_rank_stops_every_rank(tmp_path):
     assert T.decode(st1)[0] == 14                       # the failing rank returns its operator's status
     assert st0 != 0 and T.decode(st0)[0] == 2           # the other one: stopped by a peer (LAUNCH_FAILED class)
     assert calls1 in (5, 6) and calls0 in (5, 6)        # both stopped in the slot of the failure (2 operator calls per iteration), far from the 300 iterations asked for
+
+
+@pytest.mark.parametrize("how", ["nobuffer", "operator"])
+def test_a_refusing_rank_ends_a_mixed_precision_solve_on_every_rank(tmp_path, how):
+    """'m' plans: a rank that cannot start -- no work buffer, or a user-defined operator, which mixed-precision plans refuse --
+    takes part in the FIRST collective its peers enter, the refinement's max-reduction of 3 doubles, with "a rank failed" set; every rank
+    leaves there: same number and sizes of reductions on both ranks, the refusing rank returns its own status (7 | 19), the other one 2."""
+    out = str(tmp_path / "status.txt")
+    env = dict(os.environ, OMP_NUM_THREADS="2", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = torchrun(2) + [os.path.join(ROOT, "tests", "_gpu_mixed_fail_worker.py"), out, "1", how]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)    # a hang would end here
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rows = sorted(line.split() for line in open(out))
+    assert len(rows) == 2
+    (r0, st0, n0, sz0), (r1, st1, n1, sz1) = rows
+    assert T.decode(int(st1))[0] == (7 if how == "nobuffer" else 19)      # the refusing rank: its own status
+    assert int(st0) != 0 and T.decode(int(st0))[0] == 2                   # its peer: stopped by a rank's failure
+    assert n0 == n1 == "1" and sz0 == sz1 == "3"                          # ONE collective, the same on both: the refinement's {res^2, not finite, a rank failed}

@@ -48,8 +48,6 @@ DevPlan resolve(Plan const& p) {
     d.subset = (uint32_t*)at(p.wSubset); d.bColPtr = (uint32_t*)at(p.wBColPtr); d.bList = (uint32_t*)at(p.wBList);
     d.u2i = (uint32_t*)at(p.wU2I); d.rowI = (uint32_t*)at(p.wRowI); d.origCol = (int32_t*)at(p.wOrigCol);
     d.colBatch = p.colBatch.empty() ? nullptr : (uint8_t const*)at(p.wColBatch);
-    d.orderP = p.chunks.orderP.empty() ? nullptr : (uint32_t const*)at(p.wOrderP); d.nWGp = uint32_t(p.chunks.orderP.size() / 4);
-    d.orderC = p.chunks.orderC.empty() ? nullptr : (uint32_t const*)at(p.wOrderC); d.nChunksC = uint32_t(p.chunks.orderC.size());
     d.orderB = p.colBatch.empty() ? nullptr : (uint32_t const*)at(p.wOrderB); d.nChunksB = uint32_t(p.chunks.orderB.size());
     return d;
 }
@@ -248,6 +246,15 @@ static tfqmrgpuStatus_t run_tfqmr(Handle& h, Plan& p, DevPlan const& dIn, double
     // over ranks or a foreign multiply sits between the producer and the decision otherwise)
     bool const fold = p.foldOk && !multi && !p.opFn;
     DevPlan const d = [&] { DevPlan x = dIn; x.fold = fold ? 1 : 0; return x; }();
+    if (fold && p.selfStale) {
+        // the device-resident copy that the folded column operations read: taken again whenever a plan flag has changed since the last
+        // one (hashV3, m3: setShadowVector / setShadowMode / setThreeProductMultiply; the copy of setBuffer predates the shadow vector),
+        // so that device code never sees a flag that the host's DevPlan does not have
+        DevPlan self = d; self.fold = 1; self.first = 0;
+        TFQ_HIP(hipMemcpyAsync((void*)d.self, &self, sizeof self, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        p.selfStale = false;
+    }
     constexpr int DEPTH = Plan::kDepth;
     constexpr int NK = TFQMRGPU_PROFILE_CLASSES;
     // How far the host runs ahead: 2 slots.  Every slot that is still queued when the solve stops costs ~14 empty
@@ -470,8 +477,25 @@ struct FlopModel {
 static tfqmrgpuStatus_t run_mixed(Handle& h, Plan& p, double tol, int maxIt) {
     hipStream_t const s = (hipStream_t)h.stream;
     SolveOutcome o;
-    if (!p.buffer)  return run_tfqmr(h, p, DevPlan{}, tol, maxIt, TFQ_ERR(TFQMRGPU_POINTER_INVALID), 1., o);   // (the refusal travels through the ranks' vote)
-    if (p.opFn)     return run_tfqmr(h, p, DevPlan{}, tol, maxIt, TFQ_ERR(TFQMRGPU_NO_IMPLEMENTATION), 1., o);  // user-defined operators: 'z' and 'c' only
+    bool const multi = (h.comm != nullptr) || (h.reduceFn != nullptr);
+    // ONE failure protocol for several ranks: the first collective of a mixed-precision solve is the refinement's
+    // max-reduction of {max |r|^2/|b|^2, a value is not finite, a rank failed} (3 doubles) -- not the vote of run_tfqmr (2 doubles).  A
+    // rank that cannot start (no buffer; a user-defined operator, which 'm' plans refuse) therefore takes part in THAT reduction with
+    // the third value set: its peers read it in their cycle 0 and every rank leaves at the same collective, the refusing one with
+    // its own status, the others with "a peer failed".  A rank that fails later, between two collectives, hands its failure to the
+    // next one it would have entered: the vote of the inner solve (`early`), or the next refinement reduction (`mine`).
+    auto const leave_marked = [&](tfqmrgpuStatus_t st) -> tfqmrgpuStatus_t {
+        if (!multi) return st;
+        if (!h.voteBuf) return st;                           // (allocated with the communicator / callback; without it no collective can be entered)
+        double const mark[3] = { 0., 0., 1. };
+        if (hipSuccess != hipMemcpyAsync(h.voteBuf, mark, sizeof mark, hipMemcpyHostToDevice, s)) return st;
+        if (hipSuccess != hipStreamSynchronize(s)) return st;
+        (void)reduce_over_ranks(h, h.voteBuf, 3, s);
+        (void)hipStreamSynchronize(s);
+        return st;
+    };
+    if (!p.buffer)  return leave_marked(TFQ_ERR(TFQMRGPU_POINTER_INVALID));
+    if (p.opFn)     return leave_marked(TFQ_ERR(TFQMRGPU_NO_IMPLEMENTATION));  // user-defined operators: 'z' and 'c' only
     DevPlan const d = resolve(p), dz = resolveZ(p);
     FlopModel const fm(p);
     RefineArgs a{};
@@ -485,16 +509,23 @@ static tfqmrgpuStatus_t run_mixed(Handle& h, Plan& p, double tol, int maxIt) {
     bool brokeDown = false;
     double res2 = 1e300, prev2 = 1e300, bestGain = 1.;
     tfqmrgpuStatus_t result = TFQMRGPU_STATUS_MAX_ITERATIONS;
+    tfqmrgpuStatus_t mine = TFQMRGPU_STATUS_SUCCESS;     // this rank's own failure between two collectives: rides the next refinement reduction
     for (int cycle = 0; ; ++cycle) {
         if (cycle > 0) { spmm_apply(dz, dz.x, (void*)a.Yz, s); p.flops_performed += fm.fMult; }
         a.cycle = cycle; a.innerTol = 1e-4; a.innerMaxIt = std::max(0, maxIt - used);
         launch_refine_residual(a, s);
         p.flops_performed += fm.fNrm;
-        if (auto const st = reduce_over_ranks(h, a.refine, 3, s)) return st;
+        if (!mine && hipSuccess != hipGetLastError()) mine = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
+        if (mine && multi) {   // (k_refine_max has written {.., .., 0}: this rank's mark behind it, on the same stream)
+            static double const kOne = 1.;
+            (void)hipMemcpyAsync(a.refine + 2, &kOne, sizeof kOne, hipMemcpyHostToDevice, s);
+        }
+        if (auto const st = reduce_over_ranks(h, a.refine, 3, s)) return mine ? mine : st;
+        if (mine) return mine;                                              // every rank leaves behind this reduction
         double v[3];
         TFQ_HIP(hipMemcpyAsync(v, a.refine, sizeof v, hipMemcpyDeviceToHost, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
         TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)
-        if (v[2] > 0.) return TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);      // a rank failed
+        if (v[2] > 0.) return TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);      // a rank failed: every rank reads the same value and leaves here
         res2 = v[0];
         p.cycleResidual.push_back(std::sqrt(res2));
         p.refinementCycles = cycle;
@@ -526,8 +557,12 @@ static tfqmrgpuStatus_t run_mixed(Handle& h, Plan& p, double tol, int maxIt) {
         }
         double const innerTol = std::min(0.5, std::max(kInnerFloor, ask));
         double const t2[2] = { innerTol * innerTol, innerTol * innerTol * 1e4 };   // Ctl::tol2, Ctl::target_bound2 (every rank the same values)
-        TFQ_HIP(hipMemcpyAsync(&d.ctl->tol2, t2, sizeof t2, hipMemcpyHostToDevice, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
-        if (auto const st = run_tfqmr(h, p, d, innerTol, maxIt - used, TFQMRGPU_STATUS_SUCCESS, res2, o)) return st;
+        // (a failure here travels through the vote in front of the inner solve: the peers are about to enter THAT collective)
+        tfqmrgpuStatus_t const early = (hipSuccess == hipMemcpyAsync(&d.ctl->tol2, t2, sizeof t2, hipMemcpyHostToDevice, s))
+                                       ? TFQMRGPU_STATUS_SUCCESS : TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
+        // run_tfqmr's own protocol makes every rank come back at the same point: a refusal through its vote, a failure inside through the
+        // third value of its slot records (state 4) -- so a status from it ends the refinement on every rank alike
+        if (auto const st = run_tfqmr(h, p, d, innerTol, maxIt - used, early, res2, o)) return st;
         used += o.last.iteration;
         p.cycleIterations.push_back(o.last.iteration);
         brokeDown = (2 == o.last.state);                                    // every right-hand side of this float solve broke down
@@ -722,8 +757,6 @@ tfqmrgpuStatus_t tfqmrgpu_bsrsv_setBuffer(tfqmrgpuHandle_t handle, tfqmrgpuBsrsv
     if ((st = up(p->wColStart, p->colStart.data(), p->colStart.size() * 4))) return st;
     if ((st = up(p->wOrigCol, orig.data(), orig.size() * 4))) return st;
     if (!p->colBatch.empty() && (st = up(p->wColBatch, p->colBatch.data(), p->colBatch.size()))) return st;
-    if (!c.orderP.empty() && (st = up(p->wOrderP, c.orderP.data(), c.orderP.size() * 4))) return st;
-    if (!c.orderC.empty() && (st = up(p->wOrderC, c.orderC.data(), c.orderC.size() * 4))) return st;
     if (!p->colBatch.empty() && (st = up(p->wOrderB, c.orderB.data(), c.orderB.size() * 4))) return st;
     if ((st = up(p->wBofX, p->bOfX.data(), p->bOfX.size() * 4))) return st;
     if ((st = up(p->wStarts, p->starts_i.data(), p->starts_i.size() * 4))) return st;
@@ -751,9 +784,9 @@ tfqmrgpuStatus_t tfqmrgpu_bsrsv_setBuffer(tfqmrgpuHandle_t handle, tfqmrgpuBsrsv
         for (size_t i = 0; i < n; ++i) v3[i] = rng.next() * denom;
         st = transfer_blocks(*p, s, 0, false, Target{d.v3, false, p->ilv}, v3.data(), d.u2i, p->nnzbX, p->LM, p->LN, TFQMRGPU_LAYOUT_RRRRIIII, false, false);
         if (st) return st;
-        p->v3IsHash = false;
+        p->v3IsHash = false; p->selfStale = true;
     } else {
-        p->v3IsHash = true;
+        p->v3IsHash = true; p->selfStale = true;
         launch_shadow_hash(d, s);
         if (hipSuccess != hipGetLastError()) return TFQ_ERR(TFQMRGPU_STATUS_RANDOM_GEN_FAILED);
     }
@@ -972,7 +1005,7 @@ tfqmrgpuStatus_t tfqmrgpuExt_getProfileFirst(tfqmrgpuBsrsvPlan_t plan, int64_t* 
 tfqmrgpuStatus_t tfqmrgpuExt_setThreeProductMultiply(tfqmrgpuBsrsvPlan_t plan, int on) {
     auto p = asPlan(plan);
     if (!p) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
-    p->threeProducts = (0 != on);
+    p->threeProducts = (0 != on); p->selfStale = true;
     return TFQMRGPU_STATUS_SUCCESS;
 }
 
@@ -999,7 +1032,7 @@ tfqmrgpuStatus_t tfqmrgpuExt_setShadowVector(tfqmrgpuHandle_t handle, tfqmrgpuBs
     auto p = asPlan(plan); auto h = (Handle*)handle;
     if (!p || !h || !v3 || !p->buffer) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
     DevPlan const d = resolve(*p);
-    p->v3IsHash = false;
+    p->v3IsHash = false; p->selfStale = true;
     return transfer_blocks(*p, (hipStream_t)h->stream, 0, false, Target{d.v3, false, p->ilv}, (void*)v3, d.u2i, p->nnzbX, p->LM, p->LN,
                            TFQMRGPU_LAYOUT_RRRRIIII, false, false);
 }

@@ -229,7 +229,11 @@ __device__ inline void decide_body(DevPlan const& d, int what, int phase, double
 // (An agent-scope release writes the XCD's L2 back: on a large system that costs more than the launches it saves -- measured
 // in round 1, 3 x slower -- which is why only small plans fold, Plan::fold.)
 __device__ inline bool fold_arrive(uint32_t* counter, uint32_t expected, int* lastFlag) {
-    __syncthreads();                                   // every thread's record stores are done
+    // every thread that may have written a record makes its stores visible device-wide BEFORE the barrier: a release by thread 0 alone
+    // orders thread 0's own stores only, the other waves' records might still be on their way to the L2 when the last work group reads
+    // them (folding applies to plans of at most 128 chunks, so the extra fences cost nothing measurable)
+    __threadfence();
+    __syncthreads();                                   // every thread's record stores are done and visible
     if (0 == threadIdx.x) {
         __threadfence();
         uint32_t const before = atomicAdd(counter, 1u);

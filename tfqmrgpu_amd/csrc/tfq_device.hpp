@@ -55,8 +55,6 @@ struct DevPlan {
     double *pz, *pd;                           // [nChunks][2|1][LN]
     double* colrec;                            // [nCols][2]
     uint32_t const *chunkFirst, *chunkCol, *colChunkPtr, *colStart, *bOfX, *order;
-    uint32_t const* orderP; uint32_t nWGp;      // not null: one wave per chunk, four chunks per work group (k_spmm_ilv16p), and the work groups of that launch
-    uint32_t const* orderC; uint32_t nChunksC;  // the same for the batches of four columns, one wave per column (k_spmm_ilv8c)
     uint32_t const* orderB; uint32_t nChunksB;  // launch order and size of the batched multiply: the chunks of the batches' first columns
     uint8_t const* colBatch;                   // not null: (batch size << 4) | position per block column -- columns with identical row patterns, multiplied together (k_spmm_ilv8b)
     uint32_t const *starts, *pairs, *subset, *bColPtr, *bList, *u2i, *rowI;

@@ -263,22 +263,14 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
         int const maxB = std::min(kColBatchMax, std::max(1, lab_switch("TFQMRGPU_BATCH", kColBatchMax)));
         p.colBatch.assign(p.nCols, uint8_t(1 << 4));
         bool any = false;
-        // (r04) runs of identical columns are cut into batches of kColBatchWide = 4 first -- one WAVE per column, k_spmm_ilv8c -- and what is left of a
-        // run into batches of at most kColBatchMax = 2 for k_spmm_ilv8b (all columns of a batch in one wave).  Lab: TFQMRGPU_BATCH_WIDE=0: none of four.
-        bool const wide = maxB >= 2 && lab_switch("TFQMRGPU_BATCH_WIDE", 0);
         for (uint32_t c = 0; c < p.nCols; ) {
             uint32_t const n0 = p.colStart[c + 1] - p.colStart[c];
-            uint32_t run = 1;
-            while (maxB >= 2 && c + run < p.nCols && p.colStart[c + run + 1] - p.colStart[c + run] == n0 && n0 > 0 &&
-                   std::equal(p.rowI.begin() + p.colStart[c], p.rowI.begin() + p.colStart[c + 1], p.rowI.begin() + p.colStart[c + run])) ++run;
-            for (uint32_t done = 0; done < run; ) {
-                uint32_t const left = run - done;
-                uint32_t const nb = (wide && left >= uint32_t(kColBatchWide)) ? uint32_t(kColBatchWide) : std::min(left, uint32_t(maxB));
-                for (uint32_t k = 0; k < nb; ++k) p.colBatch[c + done + k] = uint8_t((nb << 4) | k);
-                any = any || nb > 1;
-                done += nb;
-            }
-            c += run;
+            uint32_t nb = 1;
+            while (int(nb) < maxB && c + nb < p.nCols && p.colStart[c + nb + 1] - p.colStart[c + nb] == n0 && n0 > 0 &&
+                   std::equal(p.rowI.begin() + p.colStart[c], p.rowI.begin() + p.colStart[c + 1], p.rowI.begin() + p.colStart[c + nb])) ++nb;
+            for (uint32_t k = 0; k < nb; ++k) p.colBatch[c + k] = uint8_t((nb << 4) | k);
+            any = any || nb > 1;
+            c += nb;
         }
         if (!any) p.colBatch.clear();
     }
@@ -342,57 +334,24 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
                 for (uint32_t x = 0; x < 8; ++x)
                     if (begin[x] + i < begin[x + 1]) c.order[w++] = sorted[begin[x] + i];
         }
-        // One wave per chunk (k_spmm_ilv16p, 16 x 16 complex<double>): the same sorted list, the same contiguous eighths per XCD, but a
-        // work group takes FOUR consecutive entries of its XCD's part, one per wave -- the same band of block rows in the (up to) four
-        // block columns of a column group, whose waves then ask for the same A blocks at about the same time.  ~0 pads a part whose
-        // length is not a multiple of four.  Only for plans with enough chunks to fill the chip with such work groups.
-        c.orderP.clear();
-        if ('z' == iterPrec && 16 == LM && 16 == LN && 2 == p.ilv && 4 == CH && mode && lab_switch("TFQMRGPU_PIPE", 0) &&
-            n >= uint32_t(lab_switch("TFQMRGPU_PIPE_MIN", 4096))) {
-            std::vector<uint32_t> srt = sorted;
-            if (1 == lab_switch("TFQMRGPU_PIPE_SORT", 0))     // (lab) four consecutive chunks of ONE column per work group: X blocks shared instead
-                std::stable_sort(srt.begin(), srt.end(), [&](uint32_t a, uint32_t b) {
-                    uint32_t const ga = c.col[a] / G, gb = c.col[b] / G;
-                    if (ga != gb) return ga < gb;
-                    if (bandOf[a] / 4 != bandOf[b] / 4) return bandOf[a] / 4 < bandOf[b] / 4;
-                    if (c.col[a] != c.col[b]) return c.col[a] < c.col[b];
-                    return bandOf[a] < bandOf[b];
-                });
-            uint32_t const q = n / 8, r = n % 8;
-            std::vector<uint32_t> begin(9, 0);
-            for (uint32_t x = 0; x < 8; ++x) begin[x + 1] = begin[x] + q + (x < r ? 1 : 0);
-            uint32_t const perX = (q + (r ? 1 : 0) + 3) / 4;          // work groups per XCD
-            c.orderP.assign(size_t(perX) * 8 * 4, 0xffffffffu);
-            for (uint32_t i = 0; i < perX; ++i)
-                for (uint32_t x = 0; x < 8; ++x)
-                    for (uint32_t w = 0; w < 4; ++w)
-                        if (begin[x] + 4 * i + w < begin[x + 1]) c.orderP[(size_t(i) * 8 + x) * 4 + w] = srt[begin[x] + 4 * i + w];
-        }
-        c.orderB.clear(); c.orderC.clear();
+        c.orderB.clear();
         if (!p.colBatch.empty()) {   // the same order over the chunks of the batches' first columns only: every work group of that launch has work
-            // two launches: the batches of at most kColBatchMax columns (k_spmm_ilv8b: orderB) and the batches of kColBatchWide (k_spmm_ilv8c: orderC)
-            for (int widePass = 0; widePass < 2; ++widePass) {
-                std::vector<uint32_t> lead;
-                for (uint32_t ch : sorted) {
-                    uint8_t const cb = p.colBatch[c.col[ch]];
-                    if (0 == (cb & 15) && ((cb >> 4) == kColBatchWide) == (1 == widePass)) lead.push_back(ch);
-                }
-                uint32_t const nl = uint32_t(lead.size()), q = nl / 8, r = nl % 8;
-                auto& out = widePass ? c.orderC : c.orderB;
-                out = lead;
-                if (mode && n >= 64) {
-                    std::vector<uint32_t> begin(9, 0);
-                    for (uint32_t x = 0; x < 8; ++x) begin[x + 1] = begin[x] + q + (x < r ? 1 : 0);
-                    uint32_t w = 0;
-                    for (uint32_t i = 0; i <= q; ++i)
-                        for (uint32_t x = 0; x < 8; ++x)
-                            if (begin[x] + i < begin[x + 1]) out[w++] = lead[begin[x] + i];
-                }
+            std::vector<uint32_t> lead;
+            for (uint32_t ch : sorted) if (0 == (p.colBatch[c.col[ch]] & 15)) lead.push_back(ch);
+            uint32_t const nl = uint32_t(lead.size()), q = nl / 8, r = nl % 8;
+            c.orderB = lead;
+            if (mode && n >= 64) {
+                std::vector<uint32_t> begin(9, 0);
+                for (uint32_t x = 0; x < 8; ++x) begin[x + 1] = begin[x] + q + (x < r ? 1 : 0);
+                uint32_t w = 0;
+                for (uint32_t i = 0; i <= q; ++i)
+                    for (uint32_t x = 0; x < 8; ++x)
+                        if (begin[x] + i < begin[x + 1]) c.orderB[w++] = lead[begin[x] + i];
             }
         }
     }
     size_t const nChunks = p.chunks.col.size();
-    if (nChunks <= 128) { p.colBatch.clear(); p.chunks.orderB.clear(); p.chunks.orderC.clear(); }   // small plans fold their column operations into the multiplies' tails instead (below)
+    if (nChunks <= 128) { p.colBatch.clear(); p.chunks.orderB.clear(); }   // small plans fold their column operations into the multiplies' tails instead (below)
 
     size_t at = 0;
     auto take = [&](Window& w, size_t bytes) { w.offset = at; w.bytes = bytes; at = align256(at + bytes); };
@@ -424,8 +383,6 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     take(p.wOrigCol, size_t(p.nCols) * sizeof(int32_t));
     take(p.wColBatch, size_t(p.nCols));
     take(p.wOrderB, p.chunks.orderB.size() * sizeof(uint32_t));
-    take(p.wOrderP, p.chunks.orderP.size() * sizeof(uint32_t));
-    take(p.wOrderC, p.chunks.orderC.size() * sizeof(uint32_t));
     take(p.wBofX, size_t(p.nnzbX) * sizeof(uint32_t));         // B block on each X block or ~0
     take(p.wStarts, p.starts_i.size() * sizeof(uint32_t));
     take(p.wPairs, p.pairs_i.size() * sizeof(uint32_t));

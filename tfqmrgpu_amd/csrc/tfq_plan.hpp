@@ -27,8 +27,6 @@ struct ChunkTable {
     std::vector<uint32_t> col;     // [nChunks]   compressed block column
     std::vector<uint32_t> colPtr;  // [nCols+1]   first chunk of each column
     std::vector<uint32_t> order;   // [nChunks]   launch order of the multiply (XCD aware)
-    std::vector<uint32_t> orderP;  // one WAVE per chunk (k_spmm_ilv16p): work group b takes the chunks orderP[4 b .. 4 b + 3], ~0: none
-    std::vector<uint32_t> orderC;  // column batches of four, one wave per column (k_spmm_ilv8c): the chunks of those batches' first columns
     std::vector<uint32_t> orderB;  // column batches (Plan::colBatch): the chunks of the batches' first columns, in the same kind of order
 };
 
@@ -87,13 +85,13 @@ struct Plan {
     Window wPz, wPd;                           // per-chunk partial sums (double)
     Window wColRec;                            // per-column stopping-test record [nCols][2] double
     Window wChunkFirst, wChunkCol, wColChunkPtr, wColStart, wOrigCol, wBofX, wOrder;
-    Window wOrderP, wOrderC;
     Window wColBatch, wOrderB; std::vector<uint8_t> colBatch;   // batches of block columns with identical row patterns (empty: none); layoutBuffer
     Window wStarts, wPairs, wSubset, wBColPtr, wBList, wU2I, wRowI;
     // 'm' only: the solution, B and A in double; the residual of the refinement as the right-hand side of the inner (float) solve,
     // |b|^2 per right-hand side, the record of the refinement's stopping test
     Window wXz, wBz, wAz, wR, wBn2z, wRefine;
     Window wFold, wSelf;               // arrival counters [nCols + 1] and a device copy of the DevPlan for the folded column operations
+    bool selfStale = true;             // the device copy of the DevPlan (wSelf) predates a change of a plan flag (shadow vector, product form): refresh before a folded solve
     bool foldOk = false;               // few enough chunks that an iteration slot is launch latency: fold (tfq_colops.hpp)
 
     char* buffer = nullptr;            // device buffer registered by setBuffer

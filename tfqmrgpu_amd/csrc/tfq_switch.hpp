@@ -9,8 +9,6 @@ namespace tfq {
 // block columns multiplied together at most (tfq_plan.cpp: Plan::colBatch, tfq_spmm.hip: k_spmm_ilv8b; with 4 hipcc does not fit the registers of
 // three waves per SIMD without scratch)
 constexpr int kColBatchMax = 2;
-// ... and the batches of the work-group-level form, one wave per column (k_spmm_ilv8c, r04)
-constexpr int kColBatchWide = 4;
 
 inline int lab_switch(char const* name, int dflt) {
 #ifdef TFQ_LAB
