@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--multiply-reps", type=int, default=20)
     ap.add_argument("--no-hbm-multiply", action="store_true", help="skip the one-block-column (HBM-bound) multiply measurement")
     ap.add_argument("--no-mixed", action="store_true", help="skip the mixed-precision solve of the same system")
+    ap.add_argument("--no-collectives", action="store_true", help="skip pricing the stopping test's collectives on one rank (RCCL communicator / host callback)")
     ap.add_argument("--launcher", action="store_true", help="go through torch.distributed.run even for one rank")
     args = ap.parse_args()
 
@@ -334,13 +335,23 @@ def main():
             top = max((k for k in per_kernel if k in model), key=lambda k: per_kernel[k]["avg_ms"])
             rl_dominant = roof_of(top) if top != dom else None
             rl_all = {k: {kk: vv for kk, vv in roof_of(k).items() if kk in ("bound", "achieved", "unit", "frac", "avg_ms")} for k in per_kernel if k in model}
+            # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc cannot run inside this timing run): a KEPT figure, quoted only
+            # while it describes the kernel that runs -- every entry of profiles/pmc_traffic.json names the kernel family it was taken on
+            # (scripts/pmc_to_traffic.py), the library names the family of the running plan (tfqmrgpuExt_getMultiplyKernel)
             tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tp):   # HBM bytes per launch from the PMC passes of the same command (rocprofv3 --pmc cannot run inside this timing run)
-                rl["traffic"] = json.load(open(tp)).get(args.workload, {}).get(dom)
-            if rl["traffic"] is not None:
+            running = s.multiply_kernel()
+            rl["kernel_family"] = running
+            kept = json.load(open(tp)).get(args.workload) if os.path.exists(tp) else None
+            if kept is None:
+                rl["traffic_source"] = "null: no PMC pass of this workload is kept in profiles/pmc_traffic.json"
+            elif kept.get("_kernel") != running:
+                rl["traffic_source"] = "null: the kept PMC figures were taken on %s (%s, %s), this plan runs %s" % (kept.get("_kernel"), kept.get("_round"), kept.get("_sha"), running)
+            elif kept.get(dom) is not None:
+                rl["traffic"] = kept[dom]
                 rl["traffic_over_moved"] = round(rl["traffic"] / rl["algorithmic_bytes_moved"], 3)
                 rl["traffic_over_model"] = round(rl["traffic"] / rl["algorithmic_bytes_model"], 3)
-                rl["traffic_source"] = "profiles/pmc_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE of scripts/pmc_collect.sh, kept from the latest PMC run; not measured in this run)"
+                rl["traffic_source"] = ("profiles/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE of scripts/pmc_collect.sh on %s, %s at %s (kernel %s); kept, not measured in this run"
+                                        % (kept.get("_kernel"), kept.get("_round"), kept.get("_sha"), kept.get("_kernels", {}).get(dom)))
 
             # The BSR multiply Y = A*X on its own, twice:
             #  roofline_multiply            on the plan's data with the solver's kernel and element order (tfqmrgpuExt_applyOperator)
@@ -466,6 +477,43 @@ def main():
                 sm.close()
                 del mbuf
 
+            # What the stopping test's collectives cost a solve BEFORE anyone runs eight GPUs: the same solves on this one rank with
+            # (a) the library's RCCL communicator live (world size 1: two ncclAllReduce of 3 doubles per iteration slot on the solver's stream + the vote in
+            # front of every solve) and (b) the host-callback path (an identity callback: one device -> host -> device round trip per reduction), against
+            # the solves without either.  Per iteration: (ms with - ms without) / iterations.
+            collectives = None
+            if world == 1 and not distributed and not args.no_collectives:
+                def solves_ms(n):
+                    torch.cuda.synchronize()
+                    tc0, its = time.perf_counter(), 0
+                    for _ in range(n):
+                        s.solve(pr.tolerance, args.max_iterations)
+                        its += s.get_info()["iterations"]
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - tc0) / n * 1e3, its / n
+                nsol = max(3, min(10, args.steps))
+                s.solve(pr.tolerance, args.max_iterations)
+                base_ms, base_it = solves_ms(nsol)
+                collectives = dict(solves=nsol, ms_per_solve_no_communicator=round(base_ms, 3), iterations_per_solve=base_it)
+                uid1 = (C.c_char * 128)()
+                if T.lib.tfqmrgpuExt_commUniqueId(uid1) == 0 and T.lib.tfqmrgpuExt_commInit(s.handle, 1, 0, uid1) == 0:
+                    s.solve(pr.tolerance, args.max_iterations)
+                    ms_r, it_r = solves_ms(nsol)
+                    T.lib.tfqmrgpuExt_commDestroy(s.handle)
+                    collectives.update(ms_per_solve_rccl=round(ms_r, 3), iterations_per_solve_rccl=it_r,
+                                       rccl_us_per_iteration=round((ms_r - base_ms) / max(1.0, it_r) * 1e3, 2))
+                else:
+                    collectives["rccl"] = "the library could not set up an RCCL communicator of one rank on this box"
+                ident = T.REDUCE_CB(lambda ctx, values, n: None)
+                if T.lib.tfqmrgpuExt_setReduceCallback(s.handle, ident, None) == 0:
+                    s.solve(pr.tolerance, args.max_iterations)
+                    ms_c, it_c = solves_ms(nsol)
+                    T.lib.tfqmrgpuExt_setReduceCallback(s.handle, T.REDUCE_CB(0), None)
+                    collectives.update(ms_per_solve_host_callback=round(ms_c, 3), iterations_per_solve_host_callback=it_c,
+                                       host_callback_us_per_iteration=round((ms_c - base_ms) / max(1.0, it_c) * 1e3, 2))
+                collectives["note"] = ("one rank: what the reductions of the multi-GPU protocol add to this rank's own solve (launches, the vote, no fold of small plans); "
+                                       "the wire time of N > 1 ranks comes on top")
+
             S = pr.nnzbX * 2 * pr.LM * pr.LN * (8 if prec == "z" else 4)
             it_bytes = sum(model[k][0] for k in ("xpay_v6", "spmm_v4_dot", "v5_nrm", "x_v6_v7", "spmm_v5_nrm_dot"))
             it_ms = sum(v["avg_ms"] for k, v in per_kernel.items() if k != "probe")       # every class runs once per (steady) iteration
@@ -493,6 +541,9 @@ def main():
                 "roofline_multiply_hbm_bound": rh,
                 "mixed_precision": mixed,
                 "resolve": resolve,
+                "collectives": collectives,
+                "collective_overhead_us_per_iteration": None if collectives is None else {"rccl": collectives.get("rccl_us_per_iteration"),
+                                                                                           "host_callback": collectives.get("host_callback_us_per_iteration")},
                 "roofline_iteration": dict(bound="hbm", achieved=round(it_bytes / (it_ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                                            frac=round(it_bytes / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), ms_per_iteration=round(it_ms, 4),
                                            algorithmic_bytes=int(it_bytes)),

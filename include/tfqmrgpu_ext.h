@@ -63,6 +63,10 @@ tfqmrgpuStatus_t tfqmrgpuExt_getProfileGated(tfqmrgpuBsrsvPlan_t plan, int64_t *
  * read: XPAY_V6, SPMM_V4_DOT, V5_NRM and X_V6_V7 move 2, 2, 1 and 2 vectors less in that launch -- price a kernel against its
  * roof on the other launches. */
 tfqmrgpuStatus_t tfqmrgpuExt_getProfileFirst(tfqmrgpuBsrsvPlan_t plan, int64_t *launches, double *milliseconds);
+/* the kernel family that the fused multiplies of this plan run (needs the buffer: the element order and the column batches are fixed
+ * by bufferSize / setBuffer), e.g. "k_spmm_ilv16" -- so that kept profiler figures (profiles/pmc_traffic.json) can be told apart from
+ * figures of a kernel that no longer runs.  Writes at most `capacity` bytes including the terminating 0. */
+tfqmrgpuStatus_t tfqmrgpuExt_getMultiplyKernel(tfqmrgpuBsrsvPlan_t plan, char *name, int32_t capacity);
 
 /* ---- (2) shadow vector v3 -------------------------------------------------------------- */
 enum {

@@ -77,5 +77,26 @@ k)
   # the product without the probe hooks, run_mixed's failure protocol, the fenced fold: the whole GPU suite
   step 1100 r04k_tests.log python -m pytest tests -q -x -m gpu
   ;;
+l)
+  # PMC passes of config 3 (32 x 32 c) and of 16 x 16 c with the product; the kernel-family getter; a bench line with the guarded traffic figure
+  step 300 r04l_family.log python -m pytest tests/test_gpu_configs.py -q -x -k kernel_family
+  bash scripts/pmc_collect.sh gpurun_out/r04l_pmc3 stencil3d_32x32_c > gpurun_out/r04l_pmc3.log 2>&1
+  python3 scripts/pmc_summary.py gpurun_out/r04l_pmc3 > gpurun_out/r04l_pmc_32x32c.json
+  bash scripts/pmc_collect.sh gpurun_out/r04l_pmc16c st:16:16:c:96:96:16 > gpurun_out/r04l_pmc16c.log 2>&1
+  python3 scripts/pmc_summary.py gpurun_out/r04l_pmc16c > gpurun_out/r04l_pmc_16x16c.json
+  rm -rf gpurun_out/r04l_pmc3 gpurun_out/r04l_pmc16c
+  step 500 r04l_bench.json python bench.py --steps 5 --warmup 2 --no-cpu-baseline
+  tail -c 1500 gpurun_out/r04l_bench.json
+  ;;
+m)
+  # the price of the stopping test's collectives on one rank (bench.py: collectives): P2 and config 3
+  step 600 r04m_bench_p2.json python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-mixed --no-hbm-multiply
+  step 600 r04m_bench_cfg3.json python bench.py --steps 10 --warmup 2 --no-cpu-baseline --workload stencil3d_32x32_c
+  python3 -c "
+import json
+for f in ('gpurun_out/r04m_bench_p2.json', 'gpurun_out/r04m_bench_cfg3.json'):
+    p = json.loads(open(f).read().strip().splitlines()[-1]); print(f, p['ms_per_step'], json.dumps(p['collectives']))
+"
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac

@@ -289,3 +289,16 @@ def test_block_rows_beyond_the_reference_s_int_overflow(oracle):
     if oracle.have_ref():
         st, h, plan = oracle.Reference().create_plan(pr)
         assert T.decode(st)[:2] == (14, 169)
+
+
+def test_kept_profiler_figures_name_their_kernel():
+    """profiles/pmc_traffic.json (scripts/pmc_to_traffic.py): every workload entry says which kernel family, revision and round its bytes were
+    measured on -- bench.py drops `traffic` when the running plan's family differs (tfqmrgpuExt_getMultiplyKernel)"""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    entries = {k: v for k, v in d.items() if not k.startswith("_")}
+    assert entries
+    for wl, e in entries.items():
+        assert e.get("_kernel", "").startswith("k_spmm_") and e.get("_sha") and e.get("_round"), wl
+        assert e["_kernels"].get("spmm_v4_dot", "").startswith(e["_kernel"] + "<"), wl
+        assert all(isinstance(v, int) and v > 0 for k, v in e.items() if not k.startswith("_")), wl

@@ -136,3 +136,20 @@ def test_config5_one_gpu(torch_cuda, oracle):
     st, X, info = T.solve_problem(pr, "z", threshold=1e-9, max_iterations=300)
     assert st == 0 and info["residual"] <= 1e-9
     _check_solution_on_device(torch_cuda, oracle, pr, "z", X, info, 1e-9)
+
+
+@pytest.mark.parametrize("shape,prec,family", [((24, 24, 16, 16, 4), "z", "k_spmm_ilv16"), ((24, 24, 16, 16, 4), "c", "k_spmm_ilv16f"),
+                                               ((10, 10, 8, 8, 2), "z", "k_spmm_ilv8"),        # 13 chunks: the column operations are folded, no batches
+                                               ((48, 48, 8, 8, 4), "z", "k_spmm_ilv8b"),       # identical dense columns, more than 128 chunks: pairs
+                                               ((12, 12, 32, 32, 2), "c", "k_spmm_ilvf"), ((12, 12, 32, 32, 2), "z", "k_spmm_mfma"),
+                                               ((20, 20, 8, 32, 2), "z", "k_spmm_ilv8w"), ((20, 20, 8, 9, 2), "z", "k_spmm_mfma8"),
+                                               ((30, 30, 4, 5, 2), "z", "k_spmm_small4")])
+def test_the_library_names_the_kernel_family_of_a_plan(shape, prec, family):
+    """tfqmrgpuExt_getMultiplyKernel: what bench.py holds the kept profiler figures of profiles/pmc_traffic.json against (a traffic
+    figure of a kernel that no longer runs must not be quoted)"""
+    nx, ny, lm, ln, nc = shape
+    pr = PR.stencil_2d(nx, ny, lm, ln, nc, seed=3)
+    with T.Solver() as s:
+        s.create_plan(pr)
+        s.set_buffer(nbytes=s.buffer_size(lm, ln, prec))
+        assert s.multiply_kernel() == family

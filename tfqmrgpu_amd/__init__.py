@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [  # include/tfqmrgpu.h
 ]
 EXT_SYMBOLS = [  # include/tfqmrgpu_ext.h
     "tfqmrgpuExt_planView", "tfqmrgpuExt_getBoundHistory", "tfqmrgpuExt_setProfiling", "tfqmrgpuExt_getProfile",
-    "tfqmrgpuExt_getProfileGated", "tfqmrgpuExt_getProfileFirst",
+    "tfqmrgpuExt_getProfileGated", "tfqmrgpuExt_getProfileFirst", "tfqmrgpuExt_getMultiplyKernel",
     "tfqmrgpuExt_setShadowMode",
     "tfqmrgpuExt_setShadowVector", "tfqmrgpuExt_getShadowVector", "tfqmrgpuExt_getWorkVector", "tfqmrgpuExt_multiply", "tfqmrgpuExt_applyOperator", "tfqmrgpuExt_shardColumns",
     "tfqmrgpuExt_freeShard", "tfqmrgpuExt_commUniqueId", "tfqmrgpuExt_commInit",
@@ -115,6 +115,7 @@ def load_library(path=LIB_PATH):
     lib.tfqmrgpuExt_getProfile.argtypes = [P, P, P]
     lib.tfqmrgpuExt_getProfileGated.argtypes = [P, P, P]
     lib.tfqmrgpuExt_getProfileFirst.argtypes = [P, P, P]
+    lib.tfqmrgpuExt_getMultiplyKernel.argtypes = [P, P, C.c_int32]
     lib.tfqmrgpuExt_setShadowMode.argtypes = [P, I]
     lib.tfqmrgpuExt_setShadowVector.argtypes = [P, P, P]
     lib.tfqmrgpuExt_getShadowVector.argtypes = [P, P, P]
@@ -359,6 +360,12 @@ class Solver:
         fn = lib.tfqmrgpuExt_getProfileGated if gated else lib.tfqmrgpuExt_getProfileFirst if first else lib.tfqmrgpuExt_getProfile
         _check(fn(self.plan, _ptr(cnt), _ptr(ms)), "tfqmrgpuExt_getProfile")
         return {k: (int(cnt[i]), float(ms[i])) for i, k in enumerate(self.PROFILE_CLASSES)}
+
+    def multiply_kernel(self):
+        """the kernel family of this plan's fused multiplies, e.g. 'k_spmm_ilv16' (needs the buffer)"""
+        buf = C.create_string_buffer(64)
+        _check(lib.tfqmrgpuExt_getMultiplyKernel(self.plan, buf, 64), "tfqmrgpuExt_getMultiplyKernel")
+        return buf.value.decode()
 
     def close(self):
         if self.plan:

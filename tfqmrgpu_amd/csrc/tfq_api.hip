@@ -995,6 +995,15 @@ tfqmrgpuStatus_t tfqmrgpuExt_getProfileGated(tfqmrgpuBsrsvPlan_t plan, int64_t* 
     return TFQMRGPU_STATUS_SUCCESS;
 }
 
+tfqmrgpuStatus_t tfqmrgpuExt_getMultiplyKernel(tfqmrgpuBsrsvPlan_t plan, char* name, int32_t capacity) {
+    auto p = asPlan(plan);
+    if (!p || !name || capacity < 1) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    if (!p->buffer) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    DevPlan d = resolve(*p);
+    d.fold = (p->foldOk && !p->opFn) ? 1 : 0;     // (one rank: what run_tfqmr decides)
+    std::snprintf(name, size_t(capacity), "%s", spmm_kernel_family(d));
+    return TFQMRGPU_STATUS_SUCCESS;
+}
 tfqmrgpuStatus_t tfqmrgpuExt_getProfileFirst(tfqmrgpuBsrsvPlan_t plan, int64_t* launches, double* milliseconds) {
     auto p = asPlan(plan);
     if (!p || !launches || !milliseconds) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);

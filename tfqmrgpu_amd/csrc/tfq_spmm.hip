@@ -2196,6 +2196,22 @@ static SpmmArgs spmm_args(int epi, DevPlan const& d) {
 // (column batches: one work group per chunk of a batch's FIRST column, in an order of its own)
 static bool batched(DevPlan const& d) { return d.colBatch && !d.fold; }
 
+// the kernel family that spmm_go picks for this plan: the same conditions, in the same order
+char const* spmm_kernel_family(DevPlan const& d) {
+    int const LM = d.LM, LN = d.LN;
+    bool const z = d.dbl;
+    if (16 == LM && 16 == LN && z && d.ilv) return "k_spmm_ilv16";
+    if (16 == LM && 16 == LN && !z && 4 == d.ilv) return "k_spmm_ilv16f";
+    if (!z && LM % 16 == 0 && (32 == LN || 64 == LN) && 4 == d.ilv) return "k_spmm_ilvf";
+    if (8 == LM && 8 == LN && z && d.ilv) return batched(d) ? "k_spmm_ilv8b" : "k_spmm_ilv8";
+    if (8 == LM && (8 == LN || 32 == LN || 64 == LN) && !z && 4 == d.ilv) return "k_spmm_ilv8f";
+    if (8 == LM && (32 == LN || 64 == LN) && z && d.ilv) return "k_spmm_ilv8w";
+    if (LM % 16 == 0 && LN % 16 == 0) return "k_spmm_mfma";
+    if (8 == LM || (4 == LM && z && 32 == LN)) return "k_spmm_mfma8";
+    if (4 == LM) return "k_spmm_small4";
+    return "k_spmm_direct";
+}
+
 void spmm_launch(int epi, DevPlan const& d, hipStream_t s) {
     if (epi != EPI_XPAY_DOT && epi != EPI_AXPY_NRM_DOT && epi != EPI_RESIDUAL) return;
     SpmmArgs a = spmm_args(epi, d);

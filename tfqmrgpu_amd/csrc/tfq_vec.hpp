@@ -22,6 +22,9 @@ hipError_t vec_launch(int op, DevPlan const& d, double tol, int maxIt, hipStream
 // Y = A*X over the plan's pair list with a fused epilogue (EPI_* in tfq_device.hpp)
 void spmm_launch(int epi, DevPlan const& d, hipStream_t s);
 
+// the kernel family spmm_launch runs for this plan (tfqmrgpuExt_getMultiplyKernel)
+char const* spmm_kernel_family(DevPlan const& d);
+
 // Y = A*X on two X-shaped vectors of the plan, no epilogue (tfqmrgpuExt_applyOperator)
 void spmm_apply(DevPlan const& d, void const* X, void* Y, hipStream_t s);
 
