@@ -391,6 +391,20 @@ def main():
             mms_n = timed(mult, args.multiply_reps)
             rmn = roof(model["multiply"][0], model["multiply"][1], mms_n, prec)
             rmn.update(kernel="multiply on caller-owned native arrays (tfqmrgpuExt_multiply)", avg_ms=round(mms_n, 5), launches=args.multiply_reps)
+            # ... and with a launch order prepared once in front of the timed launches (tfqmrgpuExt_multiplyPrepare, mode 4: the library chooses; the
+            # reference's bench prepares its launch outside its timed loop too, bench_tfqmrgpu.cu:442-556): same listing, same bits
+            order = C.c_void_p(None)
+            T._check(T.lib.tfqmrgpuExt_multiplyPrepare(s.handle, prec.encode(), pr.LM, pr.LN, pr.nnzbX, dS.data_ptr(), dP.data_ptr(), 4, C.byref(order)), "tfqmrgpuExt_multiplyPrepare")
+
+            def mult_o(reps=1):
+                for _ in range(reps):
+                    T._check(T.lib.tfqmrgpuExt_multiplyOrdered(s.handle, prec.encode(), pr.LM, pr.LN, pr.nnzbX, dS.data_ptr(), dP.data_ptr(),
+                                                               An.data_ptr(), Xn.data_ptr(), Yn.data_ptr(), order), "tfqmrgpuExt_multiplyOrdered")
+            mult_o(2)
+            mms_o = timed(mult_o, args.multiply_reps)
+            T.lib.tfqmrgpuExt_multiplyRelease(order)
+            rmn["prepared_order"] = dict(avg_ms=round(mms_o, 5), frac=roof(model["multiply"][0], model["multiply"][1], mms_o, prec)["frac"],
+                                         prepared=bool(order.value), note="tfqmrgpuExt_multiplyPrepare mode 4, prepared outside the timed launches")
             del An, Xn, Yn
 
             # the HBM-bound corner of the multiply: the operator applied to ONE block column, every A block used once

@@ -108,6 +108,23 @@ tfqmrgpuStatus_t tfqmrgpuExt_multiply(tfqmrgpuHandle_t handle,
     uint32_t nnzbY, uint32_t const *starts_d, uint32_t const *pairs_d,
     void const *A_d, void const *X_d, void *Y_d);
 
+/* A PREPARED launch order for that product (r04).  The listing stays the caller's; which work group computes which Y block is the library's to
+ * choose, and for a listing that is multiplied many times it is chosen once, outside the caller's timed loop -- as the reference's own
+ * benchmark prepares its launch (bench_tfqmrgpu.cu:442-556 in front of the timed loop :289-440).  multiplyPrepare reads the two lists
+ * back from the device, finds block columns (Y blocks that share X blocks) and row bands (by the A indices) and leaves an XCD-aware order
+ * in device memory: mode 1 = neighbouring work groups share X and A blocks, the 8 XCDs split the block COLUMNS (every L2 sees all of A and an
+ * eighth of X); mode 3 = the XCDs split the block ROWS (an eighth of A, all of X); mode 4 = 1 or 3, whichever keeps the larger operand split
+ * (the recommended one); mode 2 = mode 1 with the work groups of most block products first; mode 0 or a shape whose kernel takes no order: *order = NULL,
+ * which multiplyOrdered treats as the caller's order.  Results are those of tfqmrgpuExt_multiply bit for bit (the same kernel computes
+ * every Y block from the same pair list).  An order belongs to ONE listing (nnzbY, starts, pairs): release it with multiplyRelease. */
+tfqmrgpuStatus_t tfqmrgpuExt_multiplyPrepare(tfqmrgpuHandle_t handle, char precision, int lm, int ln,
+    uint32_t nnzbY, uint32_t const *starts_d, uint32_t const *pairs_d, int mode, void **order);
+tfqmrgpuStatus_t tfqmrgpuExt_multiplyOrdered(tfqmrgpuHandle_t handle,
+    char precision, int lm, int ln,
+    uint32_t nnzbY, uint32_t const *starts_d, uint32_t const *pairs_d,
+    void const *A_d, void const *X_d, void *Y_d, void const *order);
+tfqmrgpuStatus_t tfqmrgpuExt_multiplyRelease(void *order);
+
 /* The same product on the data of a plan: X := A * X for the plan's operator A (as given to setMatrix('A')) and the
  * plan's X (setMatrix('X') before, getMatrix('X') afterwards), truncated to the pattern of X like every product of the
  * solver.  Uses the multiply kernel and the block / element order of the solver itself -- for 16 x 16

@@ -16,7 +16,7 @@ make -s -C $root/tfqmrgpu_amd/csrc >/dev/null
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -I$root/include -I$root/tfqmrgpu_amd/csrc -Wall -Wno-unused-function --offload-arch=gfx950 \
    -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -x hip -c $src -o $root/scripts/bin/obj_$name/tfq_spmm.o
 objs=""
-for o in tfq_api tfq_vec tfq_layout tfq_plan tfq_shard tfq_error; do objs="$objs $objdir/$o.o"; done
+for o in tfq_api tfq_vec tfq_layout tfq_plan tfq_shard tfq_error tfq_order; do objs="$objs $objdir/$o.o"; done
 objs="$objs $root/tfqmrgpu_amd/lib/obj/tfq_fortran.o"
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $root/scripts/bin/libtfQMRgpu_$name.so $root/scripts/bin/obj_$name/tfq_spmm.o $objs -Wl,-soname,libtfQMRgpu.so.1 -ldl
 rm -rf $root/scripts/bin/obj_$name

@@ -98,5 +98,35 @@ for f in ('gpurun_out/r04m_bench_p2.json', 'gpurun_out/r04m_bench_cfg3.json'):
     p = json.loads(open(f).read().strip().splitlines()[-1]); print(f, p['ms_per_step'], json.dumps(p['collectives']))
 "
   ;;
+n)
+  # the native-order multiply with a prepared launch order (tfqmrgpuExt_multiplyPrepare): config 1's plan file, P2's native listing
+  step 600 r04n_native.txt python scripts/native_order_probe.py 50
+  cat gpurun_out/r04n_native.txt
+  ;;
+o)
+  # ... and with 3 | 4 operand sets (block products in flight per wave) in the 16 x 16 plain-mode kernel (lab switch TFQMRGPU_PLAIN_NSET)
+  export TFQMRGPU_LIB=$GRAFT_REPO_ROOT/tfqmrgpu_amd/lib/libtfQMRgpu_lab.so
+  for n in 2 3 4; do
+    export TFQMRGPU_PLAIN_NSET=$n
+    echo "## TFQMRGPU_PLAIN_NSET=$n" >> gpurun_out/r04o_native.txt
+    step 600 r04o_native_$n.txt python scripts/native_order_probe.py 50
+    grep -v "mode 2" gpurun_out/r04o_native_$n.txt | sort -u >> gpurun_out/r04o_native.txt
+  done
+  cat gpurun_out/r04o_native.txt
+  ;;
+p)
+  # prepared order, the XCDs splitting the rows (mode 3) or the library choosing (4)
+  step 600 r04p_native.txt python scripts/native_order_probe.py 50
+  cat gpurun_out/r04p_native.txt
+  ;;
+q)
+  # prepared order in the tests and in both bench drivers (config 1: bench_tfqmrgpu multi)
+  step 900 r04q_tests.log python -m pytest tests/test_gpu_parity.py tests/test_bench_binary.py -q -x -k "multiply or bench or binary"
+  for p in f z; do
+    BENCH_ORDER=0 tfqmrgpu_amd/lib/bench_tfqmrgpu multi tests/golden/plan_unordered.14-287-16.gz $p 200 3 > gpurun_out/r04q_multi_${p}_order0.txt 2>&1
+    tfqmrgpu_amd/lib/bench_tfqmrgpu multi tests/golden/plan_unordered.14-287-16.gz $p 200 3 > gpurun_out/r04q_multi_${p}_order4.txt 2>&1
+    grep -h "launch order\|GPU performance\|roofline" gpurun_out/r04q_multi_${p}_order0.txt gpurun_out/r04q_multi_${p}_order4.txt
+  done
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac

@@ -208,7 +208,19 @@ def test_multiply_all_block_sizes(torch_cuda, oracle, prec, size):
                                         dA.data_ptr(), dX.data_ptr(), dY.data_ptr())
         assert st == 0
         torch.cuda.synchronize()
-    got = dY.cpu().numpy()
+        got = dY.cpu().numpy()
+        # ... and with a prepared launch order (tfqmrgpuExt_multiplyPrepare, every mode): which work group computes a Y block changes, no bit of it does
+        # (shapes whose kernel takes no order get a null order = the caller's)
+        for mode in (1, 2, 3, 4):
+            order = C.c_void_p(None)
+            assert T.lib.tfqmrgpuExt_multiplyPrepare(s.handle, prec.encode(), LM, LN, nY, dS.data_ptr(), dP.data_ptr(), mode, C.byref(order)) == 0
+            assert bool(order.value) == (LM % 16 == 0 and LN % 16 == 0)
+            dZ = torch.full((nY, 2, LM, LN), 5.0, dtype=dA.dtype, device="cuda")
+            assert T.lib.tfqmrgpuExt_multiplyOrdered(s.handle, prec.encode(), LM, LN, nY, dS.data_ptr(), dP.data_ptr(),
+                                                     dA.data_ptr(), dX.data_ptr(), dZ.data_ptr(), order) == 0
+            torch.cuda.synchronize()
+            assert np.array_equal(dZ.cpu().numpy(), got), (size, prec, mode)
+            assert T.lib.tfqmrgpuExt_multiplyRelease(order) == 0
     eps = 1e-13 if prec == "z" else 2e-5
     assert np.abs(got - Yw).max() <= eps * LM * 6, (size, prec)
     del want
@@ -254,7 +266,21 @@ def test_multiply_reference_plan_file(torch_cuda, oracle, prec):
         assert T.lib.tfqmrgpuExt_multiply(s.handle, prec.encode(), LM, LN, nY, dS.data_ptr(), dP.data_ptr(),
                                           dA.data_ptr(), dX.data_ptr(), dY.data_ptr()) == 0
         torch.cuda.synchronize()
-    dev = np.abs(dY.cpu().numpy() - want).max()
+        got = dY.cpu().numpy()
+        # with a prepared order (mode 4: the library chooses how the XCDs split the listing -- here the rows, A outweighs X): the same bits; an order
+        # is refused for another listing
+        for mode in (1, 3, 4):
+            order = C.c_void_p(None)
+            assert T.lib.tfqmrgpuExt_multiplyPrepare(s.handle, prec.encode(), LM, LN, nY, dS.data_ptr(), dP.data_ptr(), mode, C.byref(order)) == 0 and order.value
+            dZ = torch.zeros_like(dX)
+            assert T.lib.tfqmrgpuExt_multiplyOrdered(s.handle, prec.encode(), LM, LN, nY, dS.data_ptr(), dP.data_ptr(),
+                                                     dA.data_ptr(), dX.data_ptr(), dZ.data_ptr(), order) == 0
+            torch.cuda.synchronize()
+            assert np.array_equal(dZ.cpu().numpy(), got), mode
+            assert T.decode(T.lib.tfqmrgpuExt_multiplyOrdered(s.handle, prec.encode(), LM, LN, nY - 1, dS.data_ptr(), dP.data_ptr(),
+                                                              dA.data_ptr(), dX.data_ptr(), dZ.data_ptr(), order))[0] == 7
+            assert T.lib.tfqmrgpuExt_multiplyRelease(order) == 0
+    dev = np.abs(got - want).max()
     assert dev <= (1e-12 if prec == "z" else 1e-4), dev
 
 

@@ -34,7 +34,7 @@ EXT_SYMBOLS = [  # include/tfqmrgpu_ext.h
     "tfqmrgpuExt_planView", "tfqmrgpuExt_getBoundHistory", "tfqmrgpuExt_setProfiling", "tfqmrgpuExt_getProfile",
     "tfqmrgpuExt_getProfileGated", "tfqmrgpuExt_getProfileFirst", "tfqmrgpuExt_getMultiplyKernel",
     "tfqmrgpuExt_setShadowMode",
-    "tfqmrgpuExt_setShadowVector", "tfqmrgpuExt_getShadowVector", "tfqmrgpuExt_getWorkVector", "tfqmrgpuExt_multiply", "tfqmrgpuExt_applyOperator", "tfqmrgpuExt_shardColumns",
+    "tfqmrgpuExt_setShadowVector", "tfqmrgpuExt_getShadowVector", "tfqmrgpuExt_getWorkVector", "tfqmrgpuExt_multiply", "tfqmrgpuExt_multiplyPrepare", "tfqmrgpuExt_multiplyOrdered", "tfqmrgpuExt_multiplyRelease", "tfqmrgpuExt_applyOperator", "tfqmrgpuExt_shardColumns",
     "tfqmrgpuExt_freeShard", "tfqmrgpuExt_commUniqueId", "tfqmrgpuExt_commInit",
     "tfqmrgpuExt_commDestroy", "tfqmrgpuExt_setReduceCallback", "tfqmrgpuExt_setOperator",
     "tfqmrgpuExt_getRefinementHistory", "tfqmrgpuExt_setThreeProductMultiply",
@@ -121,6 +121,9 @@ def load_library(path=LIB_PATH):
     lib.tfqmrgpuExt_getShadowVector.argtypes = [P, P, P]
     lib.tfqmrgpuExt_getWorkVector.argtypes = [P, P, C.c_int, P]
     lib.tfqmrgpuExt_multiply.argtypes = [P, C.c_char, I, I, C.c_uint32, P, P, P, P, P]
+    lib.tfqmrgpuExt_multiplyPrepare.argtypes = [P, C.c_char, I, I, C.c_uint32, P, P, I, C.POINTER(C.c_void_p)]
+    lib.tfqmrgpuExt_multiplyOrdered.argtypes = [P, C.c_char, I, I, C.c_uint32, P, P, P, P, P, P]
+    lib.tfqmrgpuExt_multiplyRelease.argtypes = [P]
     lib.tfqmrgpuExt_applyOperator.argtypes = [P, P, I]
     lib.tfqmrgpuExt_shardColumns.argtypes = [I, P, I, P, P, I, P, I, I, I, C.POINTER(Shard)]
     lib.tfqmrgpuExt_freeShard.argtypes = [C.POINTER(Shard)]

@@ -54,8 +54,15 @@ def multi(argv):
     dS, dP = torch.from_numpy(starts.view(np.int32)).cuda(), torch.from_numpy(pairs.view(np.int32)).cuda()
     s = T.Solver()
     times, nflop = [], 0.0
-    fn = T.lib.tfqmrgpuExt_multiply      # arguments bound once: the loop below should time the library, not Python
-    call = (s.handle, prec.encode(), lm, ln, nY, dS.data_ptr(), dP.data_ptr(), dA.data_ptr(), dX.data_ptr(), dY.data_ptr())
+    # the launch order is prepared once, in front of the timed loop, as the reference prepares its launch there (bench_tfqmrgpu.cu:442-556 in front of
+    # :289-440); mode 4: the library chooses how the XCDs split the listing; BENCH_ORDER=0: the caller's order.  Same bits either way.
+    import ctypes as C
+    import os
+    order = C.c_void_p(None)
+    T._check(T.lib.tfqmrgpuExt_multiplyPrepare(s.handle, prec.encode(), lm, ln, nY, dS.data_ptr(), dP.data_ptr(), int(os.environ.get("BENCH_ORDER", 4)), C.byref(order)), "multiplyPrepare")
+    print("# launch order: %s" % ("prepared by the library (tfqmrgpuExt_multiplyPrepare)" if order.value else "the listing's own"))
+    fn = T.lib.tfqmrgpuExt_multiplyOrdered      # arguments bound once: the loop below should time the library, not Python
+    call = (s.handle, prec.encode(), lm, ln, nY, dS.data_ptr(), dP.data_ptr(), dA.data_ptr(), dX.data_ptr(), dY.data_ptr(), order)
     T._check(fn(*call), "multiply")      # warm-up (module load), as the reference's first sample is
     for _ in range(nsamp):
         torch.cuda.synchronize()
@@ -84,6 +91,7 @@ def multi(argv):
     ch = "F" if prec == "z" else "f"
     print("# GPU performed %.3f T%clop in %.3f seconds" % (nflop * 1e-12, ch, tsum))
     print("# GPU performance (lm,ln,tune)=(%3d,%3d,%d) is  %.1f G%clop/sec" % (lm, ln, 0, nflop * 1e-9 / tsum, ch))
+    T.lib.tfqmrgpuExt_multiplyRelease(order)
     s.close()
     return 0
 

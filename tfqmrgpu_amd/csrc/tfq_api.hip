@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 
 #include "tfq_device.hpp"
+#include "tfq_order.hpp"
 #include "tfq_vec.hpp"
 #include "tfq_switch.hpp"
 
@@ -1073,6 +1074,58 @@ tfqmrgpuStatus_t tfqmrgpuExt_getWorkVector(tfqmrgpuHandle_t handle, tfqmrgpuBsrs
                                         TFQMRGPU_LAYOUT_RRRRIIII, false, false, &st);
     (void)hipFree(st.ptr);
     return status;
+}
+
+// ---- prepared launch order of the stand-alone multiply (tfq_order.cpp) -----------------------------------------------------------
+namespace { struct MultiplyOrder { uint32_t magic = 0x6f726472u; uint32_t nY = 0; uint32_t* perm = nullptr; }; }
+
+tfqmrgpuStatus_t tfqmrgpuExt_multiplyPrepare(tfqmrgpuHandle_t handle, char precision, int lm, int ln, uint32_t nnzbY,
+    uint32_t const* starts_d, uint32_t const* pairs_d, int mode, void** order)
+{
+    auto h = (Handle*)handle;
+    if (!h || !starts_d || !pairs_d || !order) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    *order = nullptr;
+    if (!blockSizeAllowed(lm, ln)) return err(TFQMRGPU_BLOCKSIZE_MISSING, ln, lm);
+    uint32_t const ch = multiply_blocks_per_work_group(precision, lm, ln);
+    if (0 == ch || 0 == nnzbY || mode <= 0) return TFQMRGPU_STATUS_SUCCESS;      // nothing to prepare: a null order is the caller's order
+    hipStream_t const s = (hipStream_t)h->stream;
+    try {
+        std::vector<uint32_t> starts(size_t(nnzbY) + 1);
+        TFQ_HIP(hipMemcpyAsync(starts.data(), starts_d, starts.size() * 4, hipMemcpyDeviceToHost, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        std::vector<uint32_t> pairs(size_t(starts[nnzbY]) * 2);
+        TFQ_HIP(hipMemcpyAsync(pairs.data(), pairs_d, pairs.size() * 4, hipMemcpyDeviceToHost, s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        TFQ_HIP(hipStreamSynchronize(s), TFQMRGPU_STATUS_LAUNCH_FAILED)
+        for (uint32_t y = 0; y < nnzbY; ++y) if (starts[y + 1] < starts[y]) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
+        auto const perm = multiply_order(nnzbY, starts.data(), pairs.data(), ch, mode, uint32_t(lm * lm), uint32_t(lm * ln));
+        auto* o = new MultiplyOrder;
+        o->nY = nnzbY;
+        if (hipSuccess != hipMalloc((void**)&o->perm, size_t(nnzbY) * 4)) { delete o; return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED); }
+        if (hipSuccess != hipMemcpyAsync(o->perm, perm.data(), size_t(nnzbY) * 4, hipMemcpyHostToDevice, s) || hipSuccess != hipStreamSynchronize(s)) {
+            (void)hipFree(o->perm); delete o; return TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
+        }
+        *order = o;
+    } catch (std::bad_alloc const&) { return TFQ_ERR(TFQMRGPU_STATUS_ALLOCATION_FAILED); }
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+tfqmrgpuStatus_t tfqmrgpuExt_multiplyRelease(void* order) {
+    auto o = (MultiplyOrder*)order;
+    if (!o) return TFQMRGPU_STATUS_SUCCESS;
+    if (o->magic != 0x6f726472u) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    if (o->perm) (void)hipFree(o->perm);
+    o->magic = 0; delete o;
+    return TFQMRGPU_STATUS_SUCCESS;
+}
+
+tfqmrgpuStatus_t tfqmrgpuExt_multiplyOrdered(tfqmrgpuHandle_t handle, char precision, int lm, int ln,
+    uint32_t nnzbY, uint32_t const* starts_d, uint32_t const* pairs_d, void const* A_d, void const* X_d, void* Y_d, void const* order)
+{
+    auto h = (Handle*)handle;
+    if (!h || !starts_d || !pairs_d || !A_d || !X_d || !Y_d) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);
+    auto o = (MultiplyOrder const*)order;
+    if (o && (o->magic != 0x6f726472u || o->nY != nnzbY)) return TFQ_ERR(TFQMRGPU_POINTER_INVALID);   // an order belongs to ONE listing
+    return launch_multiply(precision, lm, ln, nnzbY, starts_d, pairs_d, A_d, X_d, Y_d, (hipStream_t)h->stream, o ? o->perm : nullptr);
 }
 
 tfqmrgpuStatus_t tfqmrgpuExt_multiply(tfqmrgpuHandle_t handle, char precision, int lm, int ln,

@@ -131,8 +131,10 @@ void launch_decide(DevPlan const& d, int phase, hipStream_t s); // phase 0: all,
 void launch_probe_decide(DevPlan const& d, int phase, hipStream_t s);
 
 // y[iY] = sum A*X over the pair list, device pointers, native layout (tfqmrgpu_ext.h section 3)
+// yOrder (device, optional): a prepared launch order, position i of the launch computes Y block yOrder[i] (tfq_order.cpp)
 tfqmrgpuStatus_t launch_multiply(char precision, int lm, int ln, uint32_t nnzbY,
-    uint32_t const* starts, uint32_t const* pairs, void const* A, void const* X, void* Y, hipStream_t s);
+    uint32_t const* starts, uint32_t const* pairs, void const* A, void const* X, void* Y, hipStream_t s, uint32_t const* yOrder = nullptr);
+uint32_t multiply_blocks_per_work_group(char precision, int lm, int ln);   // Y blocks per work group of that launch (0: this shape's kernel takes no prepared order)
 
 // layout conversion between the caller's block layout and the native one (tfq_layout.hip)
 // direction 0: user -> native (setMatrix), 1: native -> user (getMatrix); one batch of user blocks

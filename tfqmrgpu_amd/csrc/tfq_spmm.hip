@@ -64,6 +64,7 @@ struct SpmmArgs {
     int m3;                            // double shapes above 16 x 16: three real products per complex one (tfqmrgpuExt_setThreeProductMultiply)
     DevPlan const* foldPlan;           // not null: the column operation that consumes this launch's records runs in its tail (tfq_colops.hpp)
     uint8_t const* colBatch; uint32_t const* colStart; uint32_t const* colChunkPtr;   // k_spmm_ilv8b: (batch size << 4) | position per block column; block / chunk ranges of the columns
+    uint32_t const* yOrder;            // plain mode, not null: a prepared order (tfq_order.cpp) -- position i of the launch computes Y block yOrder[i]
     uint32_t plainPer;                 // plain mode of k_spmm_mfma, not 0: XCD x (work groups x, x + 8, ...) takes the chunks [x * plainPer, (x + 1) * plainPer)
 };
 
@@ -507,8 +508,10 @@ __global__ __launch_bounds__(256, 2) void k_spmm_mfma(SpmmArgs a) {   // at leas
     double part[NPL > 0 ? NPL : 1][NT] = {};
 
     uint32_t const nUnits = (last - first) * MU;     // unit = strip of MS * 16 rows of one Y block
+    using CU32o = __attribute__((address_space(4))) uint32_t const*;
+    CU32o const yOrder = (CU32o)(uintptr_t)a.yOrder;
     for (uint32_t u = wave; u < nUnits; u += 4) {
-        uint32_t const y = first + u / MU;
+        uint32_t const y = a.yOrder ? yOrder[first + u / MU] : first + u / MU;   // (plain mode with a prepared order: which Y block this position computes)
         int const i0 = int(u % MU) * 16 * MS;
         uint64_t const key = HASH ? shadow_key(uint32_t(a.origCol[col]), a.rowI[y]) : 0;
         T4 cre[MS][NT], cim[MS][NT], cp3[M3 ? MS : 1][M3 ? NT : 1];   // M3: P1, P2, P3
@@ -2121,6 +2124,18 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
         // TFQMRGPU_DEEP=1 (lab builds): four operand sets for 32 x 32 float (measured on config 3: plain multiply 90.8 -> 94.8 TFLOP/s, but the
         // fused kernel with its epilogue prefetch spills: 0.317 -> 0.350 ms) -- off
         static int const use_deep = lab_switch("TFQMRGPU_DEEP", 0);
+        // the stand-alone multiply on the caller's listing (plain mode), 16 x 16: a wave runs the 6-14 block products of its Y block one after the
+        // other, and with two operand sets every product waits for a memory round trip -- the whole launch of BASELINE config 1's plan file
+        // (1122 work groups, all resident at once) is as long as its longest chain.  More products in flight (lab: TFQMRGPU_PLAIN_NSET = 3 | 4,
+        // unconditional prefetch with the index clamped): measured in profiles/r04_native_multiply.txt
+        if constexpr (LM == 16 && LN == 16 && EPI == EPI_NONE) {
+            static int const plainSets = lab_switch("TFQMRGPU_PLAIN_NSET", 2);
+            if (!a.chunkFirst && plainSets > 2) {
+                if (4 == plainSets) k_spmm_mfma<R, LM, LN, EPI, false, false, false, true, 4><<<dim3(nWG), dim3(256), 0, s>>>(a);
+                else k_spmm_mfma<R, LM, LN, EPI, false, false, false, true, 3><<<dim3(nWG), dim3(256), 0, s>>>(a);
+                return;
+            }
+        }
         auto go = [&](auto M3c, auto Hc) {
             constexpr bool M3 = decltype(M3c)::value, H = decltype(Hc)::value;
             if constexpr (canClamp) if (use_clamp) {
@@ -2247,13 +2262,24 @@ void epilogue_launch(int epi, DevPlan const& d, void const* Yext, uint32_t const
 #undef TFQ_CASE
 }
 
+uint32_t multiply_blocks_per_work_group(char precision, int lm, int ln) {
+    bool const dbl = ('z' == (precision | 32)) || ('d' == (precision | 32));
+    bool const mfma = (lm % 16 == 0 && ln % 16 == 0);
+    if (!mfma) return 0;                                   // (a prepared order is honoured by k_spmm_mfma only)
+    int const mt = lm / 16;
+    int const ms = (mt % 2 == 0 && 2 * (ln / 16) * (dbl ? 8 : 4) <= 32) ? 2 : 1;   // RowTiles<>::MS
+    int const mu = mt / ms;
+    return uint32_t((mu >= 4) ? 1 : 4 / mu);
+}
+
 tfqmrgpuStatus_t launch_multiply(char precision, int lm, int ln, uint32_t nnzbY,
-    uint32_t const* starts, uint32_t const* pairs, void const* A, void const* X, void* Y, hipStream_t s)
+    uint32_t const* starts, uint32_t const* pairs, void const* A, void const* X, void* Y, hipStream_t s, uint32_t const* yOrder)
 {
     bool const dbl = ('z' == (precision | 32)) || ('d' == (precision | 32));
     SpmmArgs a{};
     a.Y = Y; a.A = A; a.X = X; a.starts = starts; a.pairs = pairs; a.nY = nnzbY;
     a.chunkFirst = nullptr; a.gate = 0;
+    a.yOrder = (lm % 16 == 0 && ln % 16 == 0) ? yOrder : nullptr;
     // plain mode: enough work groups to fill 256 CUs several times, at least one strip per wave
     bool const mfma = (lm % 16 == 0 && ln % 16 == 0);
     int const mt = mfma ? lm / 16 : 1;
