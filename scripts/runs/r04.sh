@@ -128,5 +128,59 @@ q)
     grep -h "launch order\|GPU performance\|roofline" gpurun_out/r04q_multi_${p}_order0.txt gpurun_out/r04q_multi_${p}_order4.txt
   done
   ;;
+r)
+  # where the iteration of the small block shapes goes: every kernel class (AB_ALL=1), 5-point stencils of about 256 MB per vector, 4 block columns
+  export AB_ALL=1
+  for wl in st:4:4:z:512:512:4 st:4:5:z:457:457:4 st:4:8:z:362:362:4 st:8:9:z:241:241:4 st:8:10:z:228:228:4 st:16:16:z:128:128:4 st:4:4:c:724:724:4 st:4:5:c:647:647:4; do
+    echo "## $wl" >> gpurun_out/r04r_shapes.txt
+    step 300 r04r_one.txt python scripts/ab_fused.py $wl default
+    grep -v amdgpu.ids gpurun_out/r04r_one.txt >> gpurun_out/r04r_shapes.txt
+  done
+  cat gpurun_out/r04r_shapes.txt
+  ;;
+s)
+  # columns of more than 256 chunk records summed by several work groups (column_total): tests, then the column kernels on P2, configs 3 and 5, a 4-column stencil
+  step 1100 r04s_tests.log python -m pytest tests -q -x -m gpu
+  export AB_ALL=1
+  for wl in fd2d_16x16_z stencil3d_32x32_c stencil2d_8x8_z st:16:16:z:128:128:4; do
+    echo "## $wl" >> gpurun_out/r04s_ab.txt
+    step 400 r04s_one.txt python scripts/ab_fused.py $wl scripts/bin/libtfQMRgpu_r03.so default
+    grep -v amdgpu.ids gpurun_out/r04s_one.txt >> gpurun_out/r04s_ab.txt
+  done
+  cat gpurun_out/r04s_ab.txt
+  ;;
+t)
+  # columns of more than 1024 chunk records summed by several work groups: previous commit | this one, every kernel class
+  export AB_ALL=1
+  for wl in fd2d_16x16_z stencil3d_32x32_c stencil2d_8x8_z st:16:16:z:128:128:4 st:16:16:z:128:128:32; do
+    echo "## $wl" >> gpurun_out/r04t_ab.txt
+    step 400 r04t_one.txt python scripts/ab_fused.py $wl scripts/bin/libtfQMRgpu_prev.so default scripts/bin/libtfQMRgpu_prev.so default
+    grep -v amdgpu.ids gpurun_out/r04t_one.txt >> gpurun_out/r04t_ab.txt
+  done
+  cat gpurun_out/r04t_ab.txt
+  step 600 r04t_tests.log python -m pytest tests/test_gpu_configs.py tests/test_gpu_ranks.py -q -x
+  ;;
+u)
+  # the same with the shares as memory-side atomic exchanges (no fence): previous commit | this one
+  export AB_ALL=1
+  step 600 r04u_tests.log python -m pytest tests/test_gpu_configs.py tests/test_gpu_ranks.py -q -x
+  for wl in stencil3d_32x32_c stencil2d_8x8_z st:16:16:z:128:128:4 st:16:16:z:128:128:32; do
+    echo "## $wl" >> gpurun_out/r04u_ab.txt
+    step 400 r04u_one.txt python scripts/ab_fused.py $wl scripts/bin/libtfQMRgpu_prev.so default
+    grep -v amdgpu.ids gpurun_out/r04u_one.txt >> gpurun_out/r04u_ab.txt
+  done
+  cat gpurun_out/r04u_ab.txt
+  ;;
+v)
+  # segments of one round of loads (256 / LN x 16 records), columns of more than four rounds cut: whole GPU suite, then previous commit | this one
+  step 1100 r04v_tests.log python -m pytest tests -q -x -m gpu
+  export AB_ALL=1
+  for wl in fd2d_16x16_z stencil3d_32x32_c stencil2d_8x8_z st:16:16:z:128:128:4 st:16:16:z:128:128:32; do
+    echo "## $wl" >> gpurun_out/r04v_ab.txt
+    step 400 r04v_one.txt python scripts/ab_fused.py $wl scripts/bin/libtfQMRgpu_prev.so default
+    grep -v amdgpu.ids gpurun_out/r04v_one.txt >> gpurun_out/r04v_ab.txt
+  done
+  cat gpurun_out/r04v_ab.txt
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac

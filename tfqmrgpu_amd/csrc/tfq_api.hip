@@ -43,6 +43,7 @@ DevPlan resolve(Plan const& p) {
     d.z = (double*)at(p.wZ); d.d = (double*)at(p.wD); d.tau = (double*)at(p.wTau); d.var = (double*)at(p.wVar);
     d.invBn2 = (double*)at(p.wInvBn2); d.status = (int8_t*)at(p.wStatus); d.ctl = (Ctl*)at(p.wCtl);
     d.pz = (double*)at(p.wPz); d.pd = (double*)at(p.wPd); d.colrec = (double*)at(p.wColRec);
+    d.colPart = (double*)at(p.wColPart); d.colSegMax = p.colSegMax;
     d.chunkFirst = (uint32_t*)at(p.wChunkFirst); d.chunkCol = (uint32_t*)at(p.wChunkCol);
     d.colChunkPtr = (uint32_t*)at(p.wColChunkPtr); d.colStart = (uint32_t*)at(p.wColStart);
     d.order = (uint32_t*)at(p.wOrder); d.bOfX = (uint32_t*)at(p.wBofX); d.starts = (uint32_t*)at(p.wStarts); d.pairs = (uint32_t*)at(p.wPairs);

@@ -55,11 +55,101 @@ __device__ inline void column_sum(double const* part, uint32_t c0, uint32_t c1, 
         for (int p = 0; p < NPL; ++p) res[p] += s[(gg * NPL + p) * LN + t];
 }
 
+// ---- folding into the producer's tail (small systems) -----------------------------------------------------------------
+// Arrival counter: true in every thread of the LAST work group that gets here for this counter (`expected` arrivals).  The
+// records a work group has written are released device-wide before it counts itself in; the last one acquires the others'.
+// (An agent-scope release writes the XCD's L2 back: on a large system that costs more than the launches it saves -- measured
+// in round 1, 3 x slower -- which is why only small plans fold, Plan::fold.)
+__device__ inline bool fold_arrive(uint32_t* counter, uint32_t expected, int* lastFlag) {
+    // every thread that may have written a record makes its stores visible device-wide BEFORE the barrier: a release by thread 0 alone
+    // orders thread 0's own stores only, the other waves' records might still be on their way to the L2 when the last work group reads
+    // them (ADVICE r03; folding applies to plans of at most 128 chunks, so the extra fences cost nothing measurable)
+    __threadfence();
+    __syncthreads();                                   // every thread's record stores are done and visible
+    if (0 == threadIdx.x) {
+        __threadfence();
+        uint32_t const before = atomicAdd(counter, 1u);
+        int const last = (before + 1 == expected) ? 1 : 0;
+        if (last) { *counter = 0; __threadfence(); }   // ready for the next use; the other work groups' records are visible now
+        *lastFlag = last;
+    }
+    __syncthreads();
+    return *lastFlag != 0;
+}
+
+// ---- columns of many chunks: several work groups per column (r04) ------------------------------------------------------------
+// One work group per block column is 2-49 work groups on a 256-CU part: a column of BASELINE config 3, 4 or 5 has 4096 chunk records, and
+// k_dec35 / k_dec34 / k_decT took 17-35 us each there -- 9 % of config 3's iteration, 4 % of config 4's and 5's -- in a kernel that is nothing
+// but a few round trips to memory per lane group.  Long columns (col_segments below) are summed by S work groups:
+// work group `seg` sums its share of the records (contiguous, balanced: the same lane-group order as column_sum inside the share), leaves it
+// in DevPlan::colPart, and the LAST one to arrive (the column's arrival counter, fold_arrive) adds the S shares IN ORDER and runs the
+// column's update.  The order of every sum is fixed by (n, LN) alone: results do not depend on which work group is last, nor on the
+// number of ranks (a column's chunks are the same on any rank).  Short columns -- every golden fixture -- are summed by one work group exactly
+// as before.  seg < 0: one work group for the whole column whatever its length (the folded path).
+// A segment is what one work group sums in ONE round of loads (256 / LN lane groups x 16 records in flight: 256 records for LN = 16, 128 for 32); columns
+// of at most four such rounds stay with one work group -- the arrival costs a few microseconds (P2's columns of 705 records, three rounds: 11 us per
+// column kernel either way), BASELINE config 3's, 4's and 5's columns of 1024-4096 records are cut (17-37 -> 10-17 us, profiles/r04_vector_kernels.txt).
+__host__ __device__ inline uint32_t col_seg_len(int LN) { return uint32_t(256 / LN) * 16u; }
+__host__ __device__ inline uint32_t col_segments(uint32_t n, int LN) { return (n <= 4 * col_seg_len(LN)) ? 1u : (n + col_seg_len(LN) - 1) / col_seg_len(LN); }
+constexpr uint32_t kColSlot = 64;      // granule of the slot numbering below (<= the shortest segment: LN = 64)
+// the slot of (column, segment) in colPart: c0 / K + col + seg is unique for any K <= the segment length (floor(c1 / K) + 1 >= floor(c0 / K) + ceil(n / K) >= segments)
+__device__ inline size_t col_part_slot(uint32_t c0, uint32_t col, uint32_t seg) { return size_t(c0 / kColSlot) + col + seg; }
+
+template <int LN, int NPL>
+__device__ inline bool column_total(DevPlan const& d, double const* part, uint32_t col, int seg, double* s, int* lastFlag, double (&res)[NPL]) {
+    uint32_t const c0 = d.colChunkPtr[col], c1 = d.colChunkPtr[col + 1], n = c1 - c0;
+    uint32_t const S = (seg < 0) ? 1u : col_segments(n, LN);
+    if (uint32_t(seg < 0 ? 0 : seg) >= S) return false;          // (the grid has as many segments as the longest column needs)
+    if (1 == S) { column_sum<LN, NPL>(part, c0, c1, s, res); return true; }
+    uint32_t const len = (n + S - 1) / S, b0 = c0 + uint32_t(seg) * len, b1 = min(c1, b0 + len);
+    column_sum<LN, NPL>(part, b0, b1, s, res);
+    int const t = threadIdx.x;
+    // The shares travel as RETURNING atomic exchanges and are read back as device-scope atomic loads: atomics of this part execute at the memory side
+    // (MI355X_MICROARCH.md, "Global float atomics"), which is coherent for all eight XCDs -- no release / acquire FENCE anywhere.  (The first form of this
+    // scheme used fold_arrive: every thread's __threadfence() is an L2 write-back, and with 32 columns x 16 segments = 512 work groups per launch the column
+    // kernels of config 4's shard went from 37 to 77 us; profiles/r04_vector_kernels.txt.)  Only wave 0 writes (LN <= 64 lanes), and thread 0 of that wave
+    // counts the work group in: one s_waitcnt for the wave's exchanges to have returned -- i.e. to have been performed -- orders them in front of the count.
+    if (t < LN)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+            double const old = __hip_atomic_exchange(d.colPart + (col_part_slot(c0, col, uint32_t(seg)) * 3 + p) * LN + t, res[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" :: "v"(old));                     // (keeps the exchange a returning one)
+        }
+    if (t < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (0 == t) {
+        uint32_t const before = __hip_atomic_fetch_add(d.foldCount + col, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int const last = (before + 1 == S) ? 1 : 0;
+        if (last) __hip_atomic_store(d.foldCount + col, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next use
+        *lastFlag = last;
+    }
+    __syncthreads();
+    if (0 == *lastFlag) return false;
+    if (t < LN) {
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) res[p] = 0;
+        constexpr int U = 8;
+        for (uint32_t g0 = 0; g0 < S; g0 += U) {                  // the shares in order, U loads in flight
+            double v[U][NPL];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p)
+                    v[u][p] = (g0 + u < S) ? __hip_atomic_load(d.colPart + (col_part_slot(c0, col, g0 + u) * 3 + p) * LN + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (g0 + u < S)
+#pragma unroll
+                    for (int p = 0; p < NPL; ++p) res[p] += v[u][p];
+        }
+    }
+    return true;
+}
+
 // dec35: beta = z/rho, rho = z  (tfqmrgpu_linalg.hxx:50-75)
 template <typename R, int LN>
-__device__ inline void col_dec35(DevPlan const& d, uint32_t const col, double* s) {
+__device__ inline void col_dec35(DevPlan const& d, uint32_t const col, double* s, int seg, int* lastFlag) {
     double z[2];
-    column_sum<LN, 2>(d.pz, d.colChunkPtr[col], d.colChunkPtr[col + 1], s, z);
+    if (!column_total<LN, 2>(d, d.pz, col, seg, s, lastFlag, z)) return;
     int const j = threadIdx.x;
     if (j >= LN) return;
     size_t const ir = (size_t(col) * 2 + 0) * LN + j, ii = ir + LN;
@@ -80,9 +170,9 @@ __device__ inline void col_dec35(DevPlan const& d, uint32_t const col, double* s
 
 // dec34: alfa = -rho/z, c67 = z*(var*eta/rho)  (tfqmrgpu_linalg.hxx:116-151)
 template <typename R, int LN>
-__device__ inline void col_dec34(DevPlan const& d, uint32_t const col, double* s) {
+__device__ inline void col_dec34(DevPlan const& d, uint32_t const col, double* s, int seg, int* lastFlag) {
     double z[2];
-    column_sum<LN, 2>(d.pz, d.colChunkPtr[col], d.colChunkPtr[col + 1], s, z);
+    if (!column_total<LN, 2>(d, d.pz, col, seg, s, lastFlag, z)) return;
     int const j = threadIdx.x;
     if (j >= LN) return;
     size_t const ir = (size_t(col) * 2 + 0) * LN + j, ii = ir + LN;
@@ -110,9 +200,9 @@ __device__ inline void col_dec34(DevPlan const& d, uint32_t const col, double* s
 // FINAL additionally leaves the per-column record for the stopping test:
 //   colrec[col] = { max_j tau_j/|b_j|^2 , 1 if any RHS of the column is not broken down (-1/-2) }
 template <typename R, int LN, bool SETC67, bool FINAL>
-__device__ inline void col_decT(DevPlan const& d, uint32_t const col, double* s, double (*rec)[64]) {
+__device__ inline void col_decT(DevPlan const& d, uint32_t const col, double* s, double (*rec)[64], int seg, int* lastFlag) {
     double dd[1];
-    column_sum<LN, 1>(d.pd, d.colChunkPtr[col], d.colChunkPtr[col + 1], s, dd);
+    if (!column_total<LN, 1>(d, d.pd, col, seg, s, lastFlag, dd)) return;
     int const j = threadIdx.x;
     if (j < LN) {
         size_t const ir = (size_t(col) * 2 + 0) * LN + j, ii = ir + LN, i1 = size_t(col) * LN + j;
@@ -151,9 +241,9 @@ __device__ inline void col_decT(DevPlan const& d, uint32_t const col, double* s,
 // true residual per RHS of one column after the probe multiply (tfqmrgpu_core.hxx:274-286):
 //   colrec[col] = { max_j res2_j , 1 if any RHS with status 0 has res2 > tol2 }
 template <int LN>
-__device__ inline void col_probe(DevPlan const& d, uint32_t const col, double* s, double (*rec)[64]) {
+__device__ inline void col_probe(DevPlan const& d, uint32_t const col, double* s, double (*rec)[64], int seg, int* lastFlag) {
     double dd[1];
-    column_sum<LN, 1>(d.pd, d.colChunkPtr[col], d.colChunkPtr[col + 1], s, dd);
+    if (!column_total<LN, 1>(d, d.pd, col, seg, s, lastFlag, dd)) return;
     int const j = threadIdx.x;
     if (j < LN) {
         size_t const i1 = size_t(col) * LN + j;
@@ -223,28 +313,6 @@ __device__ inline void decide_body(DevPlan const& d, int what, int phase, double
 }
 
 
-// ---- folding into the producer's tail (small systems) -----------------------------------------------------------------
-// Arrival counter: true in every thread of the LAST work group that gets here for this counter (`expected` arrivals).  The
-// records a work group has written are released device-wide before it counts itself in; the last one acquires the others'.
-// (An agent-scope release writes the XCD's L2 back: on a large system that costs more than the launches it saves -- measured
-// in round 1, 3 x slower -- which is why only small plans fold, Plan::fold.)
-__device__ inline bool fold_arrive(uint32_t* counter, uint32_t expected, int* lastFlag) {
-    // every thread that may have written a record makes its stores visible device-wide BEFORE the barrier: a release by thread 0 alone
-    // orders thread 0's own stores only, the other waves' records might still be on their way to the L2 when the last work group reads
-    // them (ADVICE r03; folding applies to plans of at most 128 chunks, so the extra fences cost nothing measurable)
-    __threadfence();
-    __syncthreads();                                   // every thread's record stores are done and visible
-    if (0 == threadIdx.x) {
-        __threadfence();
-        uint32_t const before = atomicAdd(counter, 1u);
-        int const last = (before + 1 == expected) ? 1 : 0;
-        if (last) { *counter = 0; __threadfence(); }   // ready for the next use; the other work groups' records are visible now
-        *lastFlag = last;
-    }
-    __syncthreads();
-    return *lastFlag != 0;
-}
-
 enum { FOLD_DEC34 = 1, FOLD_DECT_C67 = 2, FOLD_DECT_FINAL = 3, FOLD_PROBE = 4 };
 
 // called by every thread of a work group that has just written the chunk record(s) of block column `col`
@@ -252,10 +320,10 @@ template <typename R, int LN, int WHAT>
 __device__ inline void fold_tail(DevPlan const& d, uint32_t col, ColScratch& sc) {
     uint32_t const chunksOfCol = d.colChunkPtr[col + 1] - d.colChunkPtr[col];
     if (!fold_arrive(d.foldCount + col, chunksOfCol, &sc.last)) return;
-    if constexpr (WHAT == FOLD_DEC34) col_dec34<R, LN>(d, col, sc.s);
-    else if constexpr (WHAT == FOLD_DECT_C67) col_decT<R, LN, true, false>(d, col, sc.s, sc.rec);
-    else if constexpr (WHAT == FOLD_DECT_FINAL) col_decT<R, LN, false, true>(d, col, sc.s, sc.rec);
-    else col_probe<LN>(d, col, sc.s, sc.rec);
+    if constexpr (WHAT == FOLD_DEC34) col_dec34<R, LN>(d, col, sc.s, -1, &sc.last);
+    else if constexpr (WHAT == FOLD_DECT_C67) col_decT<R, LN, true, false>(d, col, sc.s, sc.rec, -1, &sc.last);
+    else if constexpr (WHAT == FOLD_DECT_FINAL) col_decT<R, LN, false, true>(d, col, sc.s, sc.rec, -1, &sc.last);
+    else col_probe<LN>(d, col, sc.s, sc.rec, -1, &sc.last);
     if constexpr (WHAT == FOLD_DECT_FINAL || WHAT == FOLD_PROBE) {     // the column's record for the decision is written: last column decides
         if (!fold_arrive(d.foldCount + d.nCols, d.nCols, &sc.last)) return;
         decide_body(d, (WHAT == FOLD_PROBE) ? 1 : 0, 0, sc.s0, sc.s1);

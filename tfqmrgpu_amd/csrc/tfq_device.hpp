@@ -54,6 +54,8 @@ struct DevPlan {
     Ctl* ctl;
     double *pz, *pd;                           // [nChunks][2|1][LN]
     double* colrec;                            // [nCols][2]
+    double* colPart; uint32_t colSegMax;       // long columns are summed by several work groups (tfq_colops.hpp: column_total):
+                                               // their shares [slot][3][LN], and the number of segments the longest column needs (the grid's y extent)
     uint32_t const *chunkFirst, *chunkCol, *colChunkPtr, *colStart, *bOfX, *order;
     uint32_t const* orderB; uint32_t nChunksB;  // launch order and size of the batched multiply: the chunks of the batches' first columns
     uint8_t const* colBatch;                   // not null: (batch size << 4) | position per block column -- columns with identical row patterns, multiplied together (k_spmm_ilv8b)

@@ -375,6 +375,16 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     take(p.wPz, nChunks * 2 * LN * sizeof(double));
     take(p.wPd, nChunks * LN * sizeof(double));
     take(p.wColRec, size_t(p.nCols) * 2 * sizeof(double)); // per-column stopping-test record
+    {   // long columns are summed by several work groups (tfq_colops.hpp: col_segments, column_total; the same two formulas)
+        uint32_t const segLen = uint32_t(256 / LN) * 16u;
+        p.colSegMax = 1;
+        for (uint32_t jb = 0; jb < p.nCols; ++jb) {
+            uint32_t const n = p.chunks.colPtr[jb + 1] - p.chunks.colPtr[jb];
+            p.colSegMax = std::max(p.colSegMax, (n <= 4 * segLen) ? 1u : (n + segLen - 1) / segLen);
+        }
+        uint32_t const K = 64;             // kColSlot
+        take(p.wColPart, (nChunks / K + p.nCols + 2) * 3 * size_t(LN) * sizeof(double));
+    }
     take(p.wChunkFirst, (nChunks + 1) * sizeof(uint32_t));
     take(p.wChunkCol, nChunks * sizeof(uint32_t));
     take(p.wOrder, nChunks * sizeof(uint32_t));

@@ -84,6 +84,7 @@ struct Plan {
     Window wCtl;                               // device control block (see tfq_solver)
     Window wPz, wPd;                           // per-chunk partial sums (double)
     Window wColRec;                            // per-column stopping-test record [nCols][2] double
+    Window wColPart; uint32_t colSegMax = 1;   // shares of the segment work groups of long columns (tfq_colops.hpp: column_total), segments of the longest column
     Window wChunkFirst, wChunkCol, wColChunkPtr, wColStart, wOrigCol, wBofX, wOrder;
     Window wColBatch, wOrderB; std::vector<uint8_t> colBatch;   // batches of block columns with identical row patterns (empty: none); layoutBuffer
     Window wStarts, wPairs, wSubset, wBColPtr, wBList, wU2I, wRowI;

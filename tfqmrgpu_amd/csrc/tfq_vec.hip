@@ -313,32 +313,37 @@ __global__ __launch_bounds__(256) void k_x_flush(DevPlan d) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Column kernels: one work group per block column (the operations themselves: tfq_colops.hpp)
+// Column kernels: one work group per block column, several for long columns (blockIdx.y = the segment;
+// the operations themselves and the segment scheme: tfq_colops.hpp)
 template <typename R, int LN>
 __global__ __launch_bounds__(256) void k_dec35(DevPlan d) {
     if (d.ctl->state != 0) return;
     __shared__ double s[512];
-    col_dec35<R, LN>(d, blockIdx.x, s);
+    __shared__ int last;
+    col_dec35<R, LN>(d, blockIdx.x, s, int(blockIdx.y), &last);
 }
 template <typename R, int LN>
 __global__ __launch_bounds__(256) void k_dec34(DevPlan d) {
     if (d.ctl->state != 0) return;
     __shared__ double s[512];
-    col_dec34<R, LN>(d, blockIdx.x, s);
+    __shared__ int last;
+    col_dec34<R, LN>(d, blockIdx.x, s, int(blockIdx.y), &last);
 }
 template <typename R, int LN, bool SETC67, bool FINAL>
 __global__ __launch_bounds__(256) void k_decT(DevPlan d) {
     if (d.ctl->state != 0) return;
     __shared__ double s[512];
     __shared__ double rec[2][64];
-    col_decT<R, LN, SETC67, FINAL>(d, blockIdx.x, s, rec);
+    __shared__ int last;
+    col_decT<R, LN, SETC67, FINAL>(d, blockIdx.x, s, rec, int(blockIdx.y), &last);
 }
 template <int LN>
 __global__ __launch_bounds__(256) void k_probe_col(DevPlan d) {
     if (d.ctl->state != 0 || d.ctl->probe == 0) return;
     __shared__ double s[512];
     __shared__ double rec[2][64];
-    col_probe<LN>(d, blockIdx.x, s, rec);
+    __shared__ int last;
+    col_probe<LN>(d, blockIdx.x, s, rec, int(blockIdx.y), &last);
 }
 // single work group: max over the column records, then the stopping decision
 __global__ __launch_bounds__(256) void k_decide(DevPlan d, int what, int phase) {
@@ -590,7 +595,7 @@ __global__ __launch_bounds__(256) void k_refine_update(RefineArgs a) {
 
 template <typename R, int LM, int LN>
 static hipError_t vec_run(int op, DevPlan const& d, double tol, int maxIt, hipStream_t s) {
-    dim3 const grid(d.nChunks), cols(d.nCols), blk(256);
+    dim3 const grid(d.nChunks), cols(d.nCols, d.colSegMax ? d.colSegMax : 1), cols1(d.nCols), blk(256);
     switch (op) {
     case VEC_SETUP: {
         size_t const S = size_t(d.nnzbX) * 2 * LM * LN * sizeof(R);
@@ -598,7 +603,7 @@ static hipError_t vec_run(int op, DevPlan const& d, double tol, int maxIt, hipSt
         // kernels take that as given instead of reading it (DevPlan::first); v9 is written before it is read.
         // No iteration at all: x is the answer, zero.
         if (maxIt <= 0) if (auto const e = hipMemsetAsync(d.x, 0, S, s)) return e;
-        if (!d.R) k_init_col<R, LM, LN><<<cols, blk, 0, s>>>(d, tol, maxIt);   // (R: set up by k_refine_init_col, with |r|^2 from its own records)
+        if (!d.R) k_init_col<R, LM, LN><<<cols1, blk, 0, s>>>(d, tol, maxIt);   // (R: set up by k_refine_init_col, with |r|^2 from its own records)
         k_dot35<R, LM, LN><<<grid, blk, 0, s>>>(d);
     } break;
     case VEC_DEC35:    k_dec35<R, LN><<<cols, blk, 0, s>>>(d); break;
