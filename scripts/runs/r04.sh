@@ -182,5 +182,17 @@ v)
   done
   cat gpurun_out/r04v_ab.txt
   ;;
+w)
+  # folding without fences (co_store / co_load, relaxed arrival): the fold on / off bit-identity tests, then the crossover (never | always fold) by chunk count
+  step 900 r04w_tests.log python -m pytest tests/test_gpu_hash_mode.py -q -x -k "switches or previous_buffer or fold"
+  tail -n 3 gpurun_out/r04w_tests.log
+  step 900 r04w_crossover.txt python scripts/fold_crossover.py "FD:1.75,6.75,2,3,0.0,4" "FD:6,24,4,2,-0.25,4" st:16:16:z:8:8:4 st:16:16:z:16:16:4 st:16:16:z:24:24:4 st:16:16:z:32:32:4 st:16:16:z:48:48:4 st:16:16:z:64:64:4 st:16:16:z:96:96:4 st:16:16:z:128:128:4 st:16:16:c:48:48:4 st:32:32:c:24:24:2 stencil3d_32x32_c st:8:8:z:64:64:4 fd2d_16x16_z
+  grep -v amdgpu.ids gpurun_out/r04w_crossover.txt
+  ;;
+x)
+  # fold limit 384 chunks: the whole GPU suite
+  step 1100 r04x_tests.log python -m pytest tests -q -x -m gpu
+  tail -n 4 gpurun_out/r04x_tests.log
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac

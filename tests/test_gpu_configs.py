@@ -140,7 +140,7 @@ def test_config5_one_gpu(torch_cuda, oracle):
 
 @pytest.mark.parametrize("shape,prec,family", [((24, 24, 16, 16, 4), "z", "k_spmm_ilv16"), ((24, 24, 16, 16, 4), "c", "k_spmm_ilv16f"),
                                                ((10, 10, 8, 8, 2), "z", "k_spmm_ilv8"),        # 13 chunks: the column operations are folded, no batches
-                                               ((48, 48, 8, 8, 4), "z", "k_spmm_ilv8b"),       # identical dense columns, more than 128 chunks: pairs
+                                               ((48, 48, 8, 8, 4), "z", "k_spmm_ilv8b"),       # identical dense columns, 576 chunks (more than the 384 up to which plans fold instead): pairs
                                                ((12, 12, 32, 32, 2), "c", "k_spmm_ilvf"), ((12, 12, 32, 32, 2), "z", "k_spmm_mfma"),
                                                ((20, 20, 8, 32, 2), "z", "k_spmm_ilv8w"), ((20, 20, 8, 9, 2), "z", "k_spmm_mfma8"),
                                                ((30, 30, 4, 5, 2), "z", "k_spmm_small4")])

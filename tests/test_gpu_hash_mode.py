@@ -155,7 +155,7 @@ SWITCHES = [dict(TFQMRGPU_3M=1), dict(TFQMRGPU_3M=2), dict(TFQMRGPU_EPI_PREFETCH
             dict(TFQMRGPU_DEPTH=1), dict(TFQMRGPU_DEPTH=4), dict(TFQMRGPU_CHUNK_KIB=64), dict(TFQMRGPU_ORDER_G=8),
             dict(TFQMRGPU_ILV=0),     # ILV=0: 16 x 16 and 8 x 8 z plans keep the native element order (k_spmm_mfma / k_spmm_mfma8)
             dict(TFQMRGPU_A_STREAM=0), dict(TFQMRGPU_CLAMP=0),
-            dict(TFQMRGPU_FOLD_MAX=0),   # the column operations as launches of their own (plans of at most 128 chunks fold them into the producers' tails)
+            dict(TFQMRGPU_FOLD_MAX=0),   # the column operations as launches of their own (plans of at most 384 chunks fold them into the producers' tails)
             dict(TFQMRGPU_FOLD_MAX=100000),
             dict(TFQMRGPU_ILV16_LDS_KIB=60)]   # the occupancy probe of k_spmm_ilv16: unused dynamic LDS, two work groups per CU   # ... and folded where the product does not (the first fixture below has 256 chunks)
 
@@ -179,10 +179,10 @@ def test_tuning_switches_change_code_paths_not_results(tmp_path, name, prec, tol
             assert np.array_equal(got["X"], base["X"]), sw   # these change WHEN things run, never what is added to what
 
 
-@pytest.mark.parametrize("name", ["stencil:40:40:8:8:5:7:5", "stencil:36:36:8:8:2:3:5", "stencil:48:30:8:8:3:11:5"])   # batches (2, 2, 1) | (2) | (2, 1) of block columns
+@pytest.mark.parametrize("name", ["stencil:40:40:8:8:5:7:5", "stencil:60:60:8:8:2:3:5", "stencil:64:40:8:8:3:11:5"])   # batches (2, 2, 1) | (2) | (2, 1) of block columns; 500 | 450 | 480 chunks (plans of at most 384 fold their column operations instead)
 def test_column_batches_change_no_bit(tmp_path, name):
     """8 x 8 complex<double>: block columns with identical row patterns are multiplied two at a time (k_spmm_ilv8b: one A fetch for both, plans of more
-    than 128 chunks; profiles/r03_column_batches.txt).  Chunks, records and every sum are those of the one-column kernel: against the lab build with
+    than 384 chunks; profiles/r03_column_batches.txt).  Chunks, records and every sum are those of the one-column kernel: against the lab build with
     TFQMRGPU_BATCH=1 (batches off) the solve must not differ in a single bit -- iteration count, bound history, residual, solution."""
     on = _worker(tmp_path, "batched", name, "z", 1e-9)
     off = _worker(tmp_path, "single", name, "z", 1e-9, TFQMRGPU_BATCH=1)

@@ -21,7 +21,16 @@ struct ColScratch { double s[512]; double rec[2][64]; double s0[256], s1[256]; i
 // Column operations: one work group per block column.  Sum the chunk records of the column in chunk
 // order (256/LN groups of LN lanes take every G-th record, then the groups are added in order),
 // then run the scalar update for the LN right-hand sides of the column.
-template <int LN, int NPL>
+// Coherent accesses for data that ANOTHER work group of the SAME launch has written or will read (the folded column operations, the segment shares):
+// returning atomic exchanges and device-scope atomic loads.  Atomics of this part execute at the memory side (MI355X_MICROARCH.md, "Global float
+// atomics"), which all eight XCDs share -- their L2s are not coherent with each other -- so neither side needs a fence: a writer waits for its
+// exchanges to have RETURNED (s_waitcnt vmcnt(0): performed) in front of the arrival count, a reader uses co_load.
+__device__ inline void co_store(double* p, double v) { double const old = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); asm volatile("" :: "v"(old)); }
+__device__ inline double co_load(double const* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_record(double* p, double v, bool coherent) { if (coherent) co_store(p, v); else *p = v; }
+
+// COH: the records were written by other work groups of this launch (folded path)
+template <int LN, int NPL, bool COH = false>
 __device__ inline void column_sum(double const* part, uint32_t c0, uint32_t c1, double* s, double (&res)[NPL]) {
     constexpr int G = 256 / LN;      // lane groups: group g takes records c0+g, c0+g+G, ...
     constexpr int U = 16;            // records in flight per lane (independent loads; the order of the sum stays fixed).  r04: every batch is predicated, so the
@@ -35,7 +44,7 @@ __device__ inline void column_sum(double const* part, uint32_t c0, uint32_t c1, 
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) v[u][p] = (c + u * G < c1) ? part[(size_t(c + u * G) * NPL + p) * LN + j] : 0.;
+                for (int p = 0; p < NPL; ++p) v[u][p] = (c + u * G < c1) ? (COH ? co_load(part + (size_t(c + u * G) * NPL + p) * LN + j) : part[(size_t(c + u * G) * NPL + p) * LN + j]) : 0.;
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (c + u * G < c1)
@@ -56,21 +65,18 @@ __device__ inline void column_sum(double const* part, uint32_t c0, uint32_t c1, 
 }
 
 // ---- folding into the producer's tail (small systems) -----------------------------------------------------------------
-// Arrival counter: true in every thread of the LAST work group that gets here for this counter (`expected` arrivals).  The
-// records a work group has written are released device-wide before it counts itself in; the last one acquires the others'.
-// (An agent-scope release writes the XCD's L2 back: on a large system that costs more than the launches it saves -- measured
-// in round 1, 3 x slower -- which is why only small plans fold, Plan::fold.)
+// Arrival counter: true in every thread of the LAST work group that gets here for this counter (`expected` arrivals).  r04: no fence.  What a work
+// group leaves for the last one -- chunk records, per-column stopping records -- is written with co_store, the last one reads it with co_load
+// (column_sum<.., COH>, decide_body(coherent)); here every wave waits for its own exchanges to have returned, the barrier collects the waves, thread 0
+// counts the work group in with a relaxed device-scope atomic.  (r01-r03: a __threadfence() per thread and two more in thread 0 -- every one an L2
+// write-back -- which is why folding LOST from 256 chunks on; the crossover with this form: profiles/r04_small_systems.txt.)
 __device__ inline bool fold_arrive(uint32_t* counter, uint32_t expected, int* lastFlag) {
-    // every thread that may have written a record makes its stores visible device-wide BEFORE the barrier: a release by thread 0 alone
-    // orders thread 0's own stores only, the other waves' records might still be on their way to the L2 when the last work group reads
-    // them (folding applies to plans of at most 128 chunks, so the extra fences cost nothing measurable)
-    __threadfence();
-    __syncthreads();                                   // every thread's record stores are done and visible
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's record exchanges (and whatever else it had in flight) are performed
+    __syncthreads();
     if (0 == threadIdx.x) {
-        __threadfence();
-        uint32_t const before = atomicAdd(counter, 1u);
+        uint32_t const before = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int const last = (before + 1 == expected) ? 1 : 0;
-        if (last) { *counter = 0; __threadfence(); }   // ready for the next use; the other work groups' records are visible now
+        if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next use
         *lastFlag = last;
     }
     __syncthreads();
@@ -100,7 +106,7 @@ __device__ inline bool column_total(DevPlan const& d, double const* part, uint32
     uint32_t const c0 = d.colChunkPtr[col], c1 = d.colChunkPtr[col + 1], n = c1 - c0;
     uint32_t const S = (seg < 0) ? 1u : col_segments(n, LN);
     if (uint32_t(seg < 0 ? 0 : seg) >= S) return false;          // (the grid has as many segments as the longest column needs)
-    if (1 == S) { column_sum<LN, NPL>(part, c0, c1, s, res); return true; }
+    if (1 == S) { if (seg < 0) column_sum<LN, NPL, true>(part, c0, c1, s, res); else column_sum<LN, NPL>(part, c0, c1, s, res); return true; }
     uint32_t const len = (n + S - 1) / S, b0 = c0 + uint32_t(seg) * len, b1 = min(c1, b0 + len);
     column_sum<LN, NPL>(part, b0, b1, s, res);
     int const t = threadIdx.x;
@@ -111,10 +117,7 @@ __device__ inline bool column_total(DevPlan const& d, double const* part, uint32
     // counts the work group in: one s_waitcnt for the wave's exchanges to have returned -- i.e. to have been performed -- orders them in front of the count.
     if (t < LN)
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) {
-            double const old = __hip_atomic_exchange(d.colPart + (col_part_slot(c0, col, uint32_t(seg)) * 3 + p) * LN + t, res[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("" :: "v"(old));                     // (keeps the exchange a returning one)
-        }
+        for (int p = 0; p < NPL; ++p) co_store(d.colPart + (col_part_slot(c0, col, uint32_t(seg)) * 3 + p) * LN + t, res[p]);
     if (t < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (0 == t) {
         uint32_t const before = __hip_atomic_fetch_add(d.foldCount + col, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -134,7 +137,7 @@ __device__ inline bool column_total(DevPlan const& d, double const* part, uint32
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int p = 0; p < NPL; ++p)
-                    v[u][p] = (g0 + u < S) ? __hip_atomic_load(d.colPart + (col_part_slot(c0, col, g0 + u) * 3 + p) * LN + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.;
+                    v[u][p] = (g0 + u < S) ? co_load(d.colPart + (col_part_slot(c0, col, g0 + u) * 3 + p) * LN + t) : 0.;
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (g0 + u < S)
@@ -233,7 +236,7 @@ __device__ inline void col_decT(DevPlan const& d, uint32_t const col, double* s,
         if (0 == j) {
             double mx = 0, alive = 0; // max ignores NaN like std::max(a, nan) == a in the reference loop
             for (int jj = 0; jj < LN; ++jj) { if (rec[0][jj] > mx) mx = rec[0][jj]; if (rec[1][jj] > alive) alive = rec[1][jj]; }
-            d.colrec[size_t(col) * 2 + 0] = mx; d.colrec[size_t(col) * 2 + 1] = alive;
+            st_record(d.colrec + size_t(col) * 2 + 0, mx, seg < 0); st_record(d.colrec + size_t(col) * 2 + 1, alive, seg < 0);   // (folded: read by another work group of this launch)
         }
     }
 }
@@ -258,20 +261,20 @@ __device__ inline void col_probe(DevPlan const& d, uint32_t const col, double* s
     if (0 == j) {
         double mx = 0, open = 0;
         for (int jj = 0; jj < LN; ++jj) { if (rec[0][jj] > mx) mx = rec[0][jj]; if (rec[1][jj] > open) open = rec[1][jj]; }
-        d.colrec[size_t(col) * 2 + 0] = mx; d.colrec[size_t(col) * 2 + 1] = open;
+        st_record(d.colrec + size_t(col) * 2 + 0, mx, seg < 0); st_record(d.colrec + size_t(col) * 2 + 1, open, seg < 0);   // (folded: the deciding work group is another one of this launch)
     }
 }
 
 // ---- single work group: max over the column records, then the stopping decision -------------------
 // what = 0: end of an iteration (tfqmrgpu_core.hxx:239-260), 1: after a probe (:287-298)
 // phase 0: reduce + decide, 1: reduce only into ctl->red (an all-reduce follows), 2: decide only
-__device__ inline void decide_body(DevPlan const& d, int what, int phase, double* s0, double* s1) {
+__device__ inline void decide_body(DevPlan const& d, int what, int phase, double* s0, double* s1, bool coherent = false) {   // coherent: the column records come from other work groups of THIS launch (folded path)
     Ctl* c = d.ctl;
     int const t = threadIdx.x;
     if (phase != 2) {
         double a = 0, b = 0;
         for (uint32_t col = t; col < d.nCols; col += 256) {
-            double const u = d.colrec[size_t(col) * 2], v = d.colrec[size_t(col) * 2 + 1];
+            double const u = coherent ? co_load(d.colrec + size_t(col) * 2) : d.colrec[size_t(col) * 2], v = coherent ? co_load(d.colrec + size_t(col) * 2 + 1) : d.colrec[size_t(col) * 2 + 1];
             if (u > a) a = u; if (v > b) b = v;
         }
         s0[t] = a; s1[t] = b;
@@ -326,7 +329,7 @@ __device__ inline void fold_tail(DevPlan const& d, uint32_t col, ColScratch& sc)
     else col_probe<LN>(d, col, sc.s, sc.rec, -1, &sc.last);
     if constexpr (WHAT == FOLD_DECT_FINAL || WHAT == FOLD_PROBE) {     // the column's record for the decision is written: last column decides
         if (!fold_arrive(d.foldCount + d.nCols, d.nCols, &sc.last)) return;
-        decide_body(d, (WHAT == FOLD_PROBE) ? 1 : 0, 0, sc.s0, sc.s1);
+        decide_body(d, (WHAT == FOLD_PROBE) ? 1 : 0, 0, sc.s0, sc.s1, true);
     }
 }
 

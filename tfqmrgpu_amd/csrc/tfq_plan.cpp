@@ -351,7 +351,7 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
         }
     }
     size_t const nChunks = p.chunks.col.size();
-    if (nChunks <= 128) { p.colBatch.clear(); p.chunks.orderB.clear(); }   // small plans fold their column operations into the multiplies' tails instead (below)
+    if (nChunks <= size_t(lab_switch("TFQMRGPU_FOLD_MAX", kFoldMax))) { p.colBatch.clear(); p.chunks.orderB.clear(); }   // small plans fold their column operations into the multiplies' tails instead (below)
 
     size_t at = 0;
     auto take = [&](Window& w, size_t bytes) { w.offset = at; w.bytes = bytes; at = align256(at + bytes); };
@@ -404,11 +404,11 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
     take(p.wFold, (size_t(p.nCols) + 1) * sizeof(uint32_t));
     take(p.wSelf, 1024);
     // Small systems fold the column operations into the producers' tails (tfq_colops.hpp): six launches less per iteration slot.
-    // "Small" = at most 128 chunks, i.e. work groups per multiply: measured with one build and the switch (scripts/fold_crossover.py,
-    // profiles/r03_small_systems.txt) folding gains 14 % at 16 chunks, 3-7 % at 32 ... 128 and LOSES 10-14 % at 256 ... 288 (every
-    // work group pays a device-wide release + an atomic, the last one of a column runs the column's sum alone), 2 x and more from
-    // 1000 chunks on.  Lab builds: TFQMRGPU_FOLD_MAX chunks.
-    p.foldOk = (nChunks <= size_t(lab_switch("TFQMRGPU_FOLD_MAX", 128)));
+    // "Small" = at most kFoldMax = 384 chunks, i.e. work groups per multiply: measured with one build and the switch (scripts/fold_crossover.py).
+    // r03, arrivals with fences: gains below 128 chunks, LOSES 10-14 % at 256 ... 288.  r04, fence-free arrivals (co_store / co_load): 22 chunks -9 %,
+    // 256-288 chunks -6 ... -9.5 %, 576 chunks +1.6 %, 1024 and more +6 ... +27 % (every work group waits for its own stores in front of the arrival):
+    // profiles/r04_small_systems.txt.  Lab builds: TFQMRGPU_FOLD_MAX chunks.
+    p.foldOk = (nChunks <= size_t(lab_switch("TFQMRGPU_FOLD_MAX", kFoldMax)));
     take(p.wA, size_t(p.nnzbA) * 2 * LM * LM * p.realBytes);
     if (mixed) {
         // Mixed precision: float vectors for the iteration (above), and in double the solution, B, A (the refinement's residual

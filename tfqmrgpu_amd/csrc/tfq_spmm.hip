@@ -165,9 +165,11 @@ __device__ inline void epilogue(SpmmArgs const& a, size_t off, int P, R yr, R yi
 
 template <int EPI>
 __device__ inline void write_record(SpmmArgs const& a, uint32_t chunk, int LN, int p, int j, double v) {
-    if constexpr (EPI == EPI_XPAY_DOT) a.pz[(size_t(chunk) * 2 + p) * LN + j] = v;
-    else if constexpr (EPI == EPI_AXPY_NRM_DOT) { if (p < 2) a.pz[(size_t(chunk) * 2 + p) * LN + j] = v; else a.pd[size_t(chunk) * LN + j] = v; }
-    else if constexpr (EPI == EPI_RESIDUAL) a.pd[size_t(chunk) * LN + j] = v;
+    // (folded: the record is read by ANOTHER work group of this launch, the last one of the column -- coherent store, tfq_colops.hpp: co_store)
+    bool const co = (a.foldPlan != nullptr);
+    if constexpr (EPI == EPI_XPAY_DOT) st_record(a.pz + (size_t(chunk) * 2 + p) * LN + j, v, co);
+    else if constexpr (EPI == EPI_AXPY_NRM_DOT) { if (p < 2) st_record(a.pz + (size_t(chunk) * 2 + p) * LN + j, v, co); else st_record(a.pd + size_t(chunk) * LN + j, v, co); }
+    else if constexpr (EPI == EPI_RESIDUAL) st_record(a.pd + size_t(chunk) * LN + j, v, co);
 }
 
 // the column operation behind a fused multiply, run by the last work group of the column (small systems, tfq_colops.hpp)

@@ -9,6 +9,9 @@ namespace tfq {
 // block columns multiplied together at most (tfq_plan.cpp: Plan::colBatch, tfq_spmm.hip: k_spmm_ilv8b; with 4 hipcc does not fit the registers of
 // three waves per SIMD without scratch)
 constexpr int kColBatchMax = 2;
+// plans of at most this many chunks fold their column operations into the producers' tails (tfq_colops.hpp; r01-r03: 128 with fenced arrivals; r04: the
+// fence-free form gains 7-10 % up to 261 chunks and loses 2 % at 576, profiles/r04_small_systems.txt)
+constexpr int kFoldMax = 384;
 
 inline int lab_switch(char const* name, int dflt) {
 #ifdef TFQ_LAB

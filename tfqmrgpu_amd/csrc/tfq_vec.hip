@@ -121,7 +121,7 @@ __device__ inline double ordered_sum(double const* sp, int j) {
     return sum;
 }
 template <int LN, int VEC, int T, int NPL>
-__device__ inline void chunk_reduce(double (&acc)[NPL][VEC], double* s, double* out, int t, int ilv = 0) {
+__device__ inline void chunk_reduce(double (&acc)[NPL][VEC], double* s, double* out, int t, int ilv = 0, bool coherent = false) {   // coherent: folded path, tfq_colops.hpp: co_store
     __syncthreads();
     if (t < T) {
 #pragma unroll
@@ -133,7 +133,7 @@ __device__ inline void chunk_reduce(double (&acc)[NPL][VEC], double* s, double* 
     for (int e = t; e < NPL * LN; e += 256) {
         int const p = e / LN, j = e % LN;
         double const* sp = s + p * (256 * VEC);
-        out[p * LN + j] = (2 == ilv) ? ordered_sum<LN, VEC, T, 2>(sp, j) : (4 == ilv) ? ordered_sum<LN, VEC, T, 4>(sp, j) : ordered_sum<LN, VEC, T, 0>(sp, j);
+        st_record(out + p * LN + j, (2 == ilv) ? ordered_sum<LN, VEC, T, 2>(sp, j) : (4 == ilv) ? ordered_sum<LN, VEC, T, 4>(sp, j) : ordered_sum<LN, VEC, T, 0>(sp, j), coherent);
     }
 }
 
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_v5_nrm(DevPlan d) {
         };
         if (d.first) sweep(std::true_type{}); else sweep(std::false_type{});
     }
-    chunk_reduce<LN, G::VEC, G::T, 1>(acc, s, d.pd + size_t(chunk) * LN, t, d.ilv);
+    chunk_reduce<LN, G::VEC, G::T, 1>(acc, s, d.pd + size_t(chunk) * LN, t, d.ilv, d.fold != 0);
     if (d.fold) {   // small systems: the last work group of the column runs decT (tau, var, eta, c67) right here
         __shared__ ColScratch sc;
         fold_tail<R, LN, FOLD_DECT_C67>(d, col, sc);
