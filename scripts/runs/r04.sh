@@ -194,5 +194,32 @@ x)
   step 1100 r04x_tests.log python -m pytest tests -q -x -m gpu
   tail -n 4 gpurun_out/r04x_tests.log
   ;;
+y)
+  # mixed precision: the plan remembers its float floor, a short last cycle runs a predicted number of iterations without probes
+  step 900 r04y_tests.log python -m pytest tests/test_gpu_mixed.py tests/test_gpu_ranks.py -q -x
+  tail -n 3 gpurun_out/r04y_tests.log
+  export TFQMRGPU_LIB=$GRAFT_REPO_ROOT/tfqmrgpu_amd/lib/libtfQMRgpu_lab.so
+  for wl in fd2d_16x16_z stencil2d_8x8_z st:32:32:z:48:48:4 st:16:16:z:96:96:8 fd2d_16x16_z_small; do
+    for sw in "0 0" "1 0" "0 1" "1 1"; do
+      set -- $sw
+      echo "TFQMRGPU_MIXED_FLOOR=$1 TFQMRGPU_MIXED_PREDICT=$2" >> gpurun_out/r04y_mixed.txt
+      TFQMRGPU_MIXED_FLOOR=$1 TFQMRGPU_MIXED_PREDICT=$2 python scripts/mixed_trace.py $wl 2>&1 | grep -v amdgpu.ids | grep " m status" >> gpurun_out/r04y_mixed.txt
+    done
+  done
+  cat gpurun_out/r04y_mixed.txt
+  ;;
+z)
+  # mixed precision, first cycle asked for twice the remembered floor: P2 and the others again, product build
+  step 900 r04z_tests.log python -m pytest tests/test_gpu_mixed.py -q -x
+  for wl in fd2d_16x16_z stencil2d_8x8_z st:32:32:z:48:48:4 st:16:16:z:96:96:8 fd2d_16x16_z_small stencil3d_32x32_c; do
+    python scripts/mixed_trace.py $wl 2>&1 | grep -v amdgpu.ids | grep " m status" >> gpurun_out/r04z_mixed.txt
+  done
+  cat gpurun_out/r04z_mixed.txt
+  ;;
+aa)
+  # the mixed-precision tests with the remembered floor
+  step 900 r04aa_tests.log python -m pytest tests/test_gpu_mixed.py -q -x
+  tail -n 5 gpurun_out/r04aa_tests.log
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac

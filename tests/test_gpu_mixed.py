@@ -159,10 +159,24 @@ def test_mixed_P2_full_size(oracle):
             nbytes = s.buffer_size(16, 16, prec)
             s.set_buffer(nbytes=nbytes)
             s.set_matrix("A", pr.A); s.set_matrix("B", pr.B)
-            s.solve(1e-9, 2000)
+            st1 = s.solve(1e-9, 2000)
+            first_solve = s.get_info()
             s.set_profiling(1)
             st = s.solve(1e-9, 2000)
             info = s.get_info()
+            if prec == "m":
+                # (r04) the plan remembers where its first float solve ran into the float floor: the SECOND solve of the plan asks its first cycle for
+                # twice that instead of searching again, and a last cycle with less than two digits to gain runs a predicted number of iterations --
+                # fewer float iterations (21 -> 17 on this system), the same threshold reached in double arithmetic; a new A forgets the floor
+                assert st1 == 0 and first_solve["residual"] <= 1e-9
+                assert info["iterations"] <= first_solve["iterations"] and info["iterations"] <= 18, (first_solve["iterations"], info["iterations"])
+                s.set_profiling(0)
+                assert s.solve(1e-9, 2000) == 0 and s.get_info()["iterations"] == info["iterations"]       # ... and every later one like the second
+                s.set_matrix("A", pr.A)
+                assert s.solve(1e-9, 2000) == 0 and s.get_info()["iterations"] == first_solve["iterations"]   # the first solve again
+                s.set_profiling(1)
+                st = s.solve(1e-9, 2000)
+                info = s.get_info()
             prof, first = s.profile(), s.profile(first=True)
             ms = sum((prof[k][1] - first[k][1]) / max(1, prof[k][0] - first[k][0]) for k in prof if k != "probe")
             out[prec] = dict(st=st, X=s.get_matrix(), info=info, it_ms=ms, nbytes=nbytes, hist=s.refinement_history())

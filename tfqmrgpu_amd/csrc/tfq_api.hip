@@ -507,8 +507,8 @@ static tfqmrgpuStatus_t run_mixed(Handle& h, Plan& p, double tol, int maxIt) {
     // what a float solve is asked for per cycle: a quarter of what is missing, but not more digits than float iterations deliver; a solve
     // that reaches its floor earlier ends itself (Ctl::stallStop) and the next cycle continues from the double residual
     double const kInnerFloor = 3e-5;
-    int used = 0, strikes = 0;
-    bool brokeDown = false;
+    int used = 0, strikes = 0, lastIts = 0;
+    bool brokeDown = false, firstStalled = false;
     double res2 = 1e300, prev2 = 1e300, bestGain = 1.;
     tfqmrgpuStatus_t result = TFQMRGPU_STATUS_MAX_ITERATIONS;
     tfqmrgpuStatus_t mine = TFQMRGPU_STATUS_SUCCESS;     // this rank's own failure between two collectives: rides the next refinement reduction
@@ -534,7 +534,11 @@ static tfqmrgpuStatus_t run_mixed(Handle& h, Plan& p, double tol, int maxIt) {
         if (v[1] > 0.) { result = TFQMRGPU_STATUS_BREAKDOWN; break; }      // the residual is not finite
         if (res2 <= tol * tol) { result = TFQMRGPU_STATUS_SUCCESS; break; }
         if (used >= maxIt) break;
-        if (cycle > 0 && prev2 > 0. && prev2 < 1e299) bestGain = std::min(bestGain, std::sqrt(res2 / prev2));   // what the last cycle delivered
+        double lastGain = 1.;
+        if (cycle > 0 && prev2 > 0. && prev2 < 1e299) { lastGain = std::sqrt(res2 / prev2); bestGain = std::min(bestGain, lastGain); }   // what the last cycle delivered
+        // (r04) the float floor of THIS plan: where its first float solve gave up by itself (Ctl::stallStop).  The next solve of the plan -- same A, new B, the
+        // use the reference's README names (:97-104) -- asks its first cycle for twice that instead of searching for it again (P2: 9 -> 7 iterations)
+        if (1 == cycle && firstStalled && lastGain < 1.) p.mixedFloor = lastGain;
         if (cycle > 0) {   // two cycles in a row gained less than a factor 2: give up (a breakdown of the last float solve is reported as one)
             strikes = (res2 > 0.25 * prev2) ? strikes + 1 : 0;
             if (strikes >= 2) { if (brokeDown) result = TFQMRGPU_STATUS_BREAKDOWN; break; }
@@ -557,15 +561,36 @@ static tfqmrgpuStatus_t run_mixed(Handle& h, Plan& p, double tol, int maxIt) {
             int const n = std::max(1, int(std::ceil(std::log(need) / std::log(cap))));
             if (n > 1) ask = std::pow(need, 1. / n);
         }
+        static int const floorEnv = lab_switch("TFQMRGPU_MIXED_FLOOR", 1), predictEnv = lab_switch("TFQMRGPU_MIXED_PREDICT", 1);
+        if (0 == cycle && floorEnv && p.mixedFloor > 0.) ask = std::max(ask, 2. * p.mixedFloor);   // (twice the floor: the last iterations in front of a floor are its slowest)
+        // (r04) a LAST cycle that has less than two digits to gain does not search: the previous cycle's rate per iteration says how many iterations
+        // that takes (+ 1), the float solve runs them without a probe of its own -- the refinement's residual in double decides anyway -- and stops
+        // (P2's third cycle: 5 iterations and three float probes for a factor 4 -> 3 iterations and the one probe at the end)
+        int innerIts = maxIt - used;
+        bool predicted = false;
+        if (predictEnv && cycle > 0 && need >= 0.01 && lastIts > 0 && lastGain < 0.5) {
+            double const rate = std::pow(lastGain, 1. / lastIts);
+            int const want = int(std::ceil(std::log(0.5 * need) / std::log(rate))) + 1;
+            innerIts = std::min(innerIts, std::max(2, std::min(want, lastIts)));
+            ask = 0.5 * need;
+            predicted = true;
+        }
         double const innerTol = std::min(0.5, std::max(kInnerFloor, ask));
-        double const t2[2] = { innerTol * innerTol, innerTol * innerTol * 1e4 };   // Ctl::tol2, Ctl::target_bound2 (every rank the same values)
+        double const t2[2] = { innerTol * innerTol, predicted ? 0. : innerTol * innerTol * 1e4 };   // Ctl::tol2, Ctl::target_bound2 (every rank the same values; 0: no probe before the last iteration)
         // (a failure here travels through the vote in front of the inner solve: the peers are about to enter THAT collective)
         tfqmrgpuStatus_t const early = (hipSuccess == hipMemcpyAsync(&d.ctl->tol2, t2, sizeof t2, hipMemcpyHostToDevice, s))
                                        ? TFQMRGPU_STATUS_SUCCESS : TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
         // run_tfqmr's own protocol makes every rank come back at the same point: a refusal through its vote, a failure inside through the
         // third value of its slot records (state 4) -- so a status from it ends the refinement on every rank alike
-        if (auto const st = run_tfqmr(h, p, d, innerTol, maxIt - used, early, res2, o)) return st;
+        tfqmrgpuStatus_t early2 = early;
+        if (predicted) {   // the inner solve's own iteration limit (k_refine_init_col has written maxIt - used)
+            int32_t const lim = innerIts;
+            if (!early2 && hipSuccess != hipMemcpyAsync(&d.ctl->maxIterations, &lim, sizeof lim, hipMemcpyHostToDevice, s)) early2 = TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
+        }
+        if (auto const st = run_tfqmr(h, p, d, innerTol, innerIts, early2, res2, o)) return st;
         used += o.last.iteration;
+        lastIts = o.last.iteration;
+        if (0 == cycle) firstStalled = (3 == o.last.state && o.last.iteration < innerIts);   // ended by itself at its floor, not at a limit
         p.cycleIterations.push_back(o.last.iteration);
         brokeDown = (2 == o.last.state);                                    // every right-hand side of this float solve broke down
         p.flops_performed += fm.solve(o.last) - fm.fNrm;                    // (|r|^2 of the set-up is the refinement's, counted above)
@@ -825,7 +850,7 @@ static tfqmrgpuStatus_t set_or_get(tfqmrgpuHandle_t handle, tfqmrgpuBsrsvPlan_t 
     if (0 == p->LM) return TFQ_ERR(TFQMRGPU_UNDOCUMENTED_ERROR);
     uint32_t nnzb = 0; int nR = p->LM, nC = p->LN; int which = 0;
     switch (lower(var)) {
-        case 'a': nnzb = p->nnzbA; nC = p->LM; trans = !trans; which = 0; break; // A is stored transposed (tfqmrgpu.cu:514-517)
+        case 'a': nnzb = p->nnzbA; nC = p->LM; trans = !trans; which = 0; if (!is_get) p->mixedFloor = 0; break; // A is stored transposed (tfqmrgpu.cu:514-517); (a new operator: the remembered float floor goes)
         case 'b': nnzb = p->nnzbB; which = 1; break;
         case 'x': nnzb = p->nnzbX; which = 2; break;
         default: return err(TFQMRGPU_VARIABLENAME_UNKNOWN, __LINE__ % 10000, var);

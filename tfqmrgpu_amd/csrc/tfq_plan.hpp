@@ -106,6 +106,7 @@ struct Plan {
     std::vector<double> cycleResidual; // 'm': relative residual (double arithmetic) in front of every inner solve and at the end
     std::vector<int32_t> cycleIterations; // 'm': float iterations of every inner solve
     int refinementCycles = 0;
+    double mixedFloor = 0;             // 'm': the gain at which the first float solve of this plan's last solve ran into its floor (0: not known; forgotten with a new A)
     // user-defined operator (tfqmrgpu_ext.h section 5): callback, and library-owned device scratch
     // [xu | yu | i2u | colindx in the caller's block order]
     void* opFn = nullptr; void* opCtx = nullptr;
