@@ -221,5 +221,25 @@ aa)
   step 900 r04aa_tests.log python -m pytest tests/test_gpu_mixed.py -q -x
   tail -n 5 gpurun_out/r04aa_tests.log
   ;;
+ab)
+  # k_spmm_small4 with 16-byte operand pieces and four block products in flight: all-shapes tests, then previous commit | this one on the 4 x N systems
+  step 900 r04ab_tests.log python -m pytest tests/test_gpu_parity.py tests/test_gpu_mixed.py -q -x -k "block_sizes or 4x4 or fd_4"
+  tail -n 3 gpurun_out/r04ab_tests.log
+  for wl in st:4:4:z:512:512:4 st:4:5:z:457:457:4 st:4:8:z:362:362:4 st:4:4:c:724:724:4 st:4:5:c:647:647:4 st:4:8:c:512:512:4; do
+    echo "## $wl" >> gpurun_out/r04ab_ab.txt
+    step 400 r04ab_one.txt python scripts/ab_fused.py $wl scripts/bin/libtfQMRgpu_prev.so default
+    grep -v amdgpu.ids gpurun_out/r04ab_one.txt >> gpurun_out/r04ab_ab.txt
+  done
+  cat gpurun_out/r04ab_ab.txt
+  ;;
+ac)
+  # k_spmm_small4: 16-byte pieces with 1 | 2 | 4 products in flight against the previous commit
+  for wl in st:4:4:z:512:512:4 st:4:5:z:457:457:4 st:4:4:c:724:724:4; do
+    echo "## $wl" >> gpurun_out/r04ac_ab.txt
+    step 400 r04ac_one.txt python scripts/ab_fused.py $wl scripts/bin/libtfQMRgpu_prev.so scripts/bin/libtfQMRgpu_s4d1.so scripts/bin/libtfQMRgpu_s4d2.so default
+    grep -v amdgpu.ids gpurun_out/r04ac_one.txt >> gpurun_out/r04ac_ab.txt
+  done
+  cat gpurun_out/r04ac_ab.txt
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac
