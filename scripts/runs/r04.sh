@@ -241,5 +241,10 @@ ac)
   done
   cat gpurun_out/r04ac_ab.txt
   ;;
+ad)
+  # what a device-wide barrier inside one cooperative launch costs against a boundary between dependent launches (scripts/grid_sync_probe.hip)
+  step 120 r04ad_grid_sync.txt scripts/bin/grid_sync_probe
+  cat gpurun_out/r04ad_grid_sync.txt
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac
