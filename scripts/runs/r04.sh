@@ -2,6 +2,8 @@
 # Every GPU call of round 4 as one parametrised script: gpurun --timeout N -- bash scripts/runs/r04.sh <step>.  A step is what was one
 # gpurun call; its comment says what it measured, profiles/r04_*.txt hold what came out (the records name the steps as "r04.sh <step>").
 source scripts/gpu_steps.sh
+# (steps a-e, j use kernels and switches that were measured and then taken out again -- k_spmm_ilv16p, k_spmm_ilv8c, scripts/pipe_bits.py: commit 34b750b has them;
+#  steps ab, ac the k_spmm_small4 variant of commit cdceff4's successor: they document how the records under profiles/ were produced, they do not run on this tree)
 case "$1" in
 a)
   # round 4, first call: one wave per chunk with a pipeline across its Y blocks (k_spmm_ilv16p): bit-identity with k_spmm_ilv16, A/B on P2
@@ -245,6 +247,37 @@ ad)
   # what a device-wide barrier inside one cooperative launch costs against a boundary between dependent launches (scripts/grid_sync_probe.hip)
   step 120 r04ad_grid_sync.txt scripts/bin/grid_sync_probe
   cat gpurun_out/r04ad_grid_sync.txt
+  ;;
+ae)
+  # the timeline of one P2 solve: kernel durations and the gaps between them (rocprofv3 --kernel-trace, scripts/trace_gaps.py)
+  cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+  rm -rf gpurun_out/r04ae_trace
+  step 300 r04ae_trace.log rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r04ae_trace -- python3 scripts/small_one.py 16 120 4 2
+  python3 scripts/trace_gaps.py gpurun_out/r04ae_trace 400 > gpurun_out/r04ae_gaps.txt
+  rm -rf gpurun_out/r04ae_trace
+  python3 - <<'PY'
+import re
+tot = gap = 0.0; n = 0; big = []
+for l in open("gpurun_out/r04ae_gaps.txt"):
+    m = re.match(r"\s*([\d.]+) us  gap\s+(-?[\d.]+)  dur\s+([\d.]+)  (.*)", l)
+    if not m: continue
+    n += 1; g = float(m.group(2)); d = float(m.group(3)); tot += d; gap += max(0.0, g)
+    if g > 6: big.append((float(m.group(1)), g, m.group(4)))
+    last = float(m.group(1)) + d
+print("kernels %d, sum of durations %.1f us, sum of gaps %.1f us, span %.1f us" % (n, tot, gap, last))
+for b in big[:30]: print("gap %.1f us at %.1f us before %s" % (b[1], b[0], b[2]))
+PY
+  ;;
+af)
+  # k_x_v6_v7 with two items per trip, loads of both in front: previous commit | this one
+  for wl in fd2d_16x16_z stencil2d_8x8_z stencil3d_32x32_c; do
+    echo "## $wl" >> gpurun_out/r04af_ab.txt
+    step 400 r04af_one.txt python scripts/ab_fused.py $wl scripts/bin/libtfQMRgpu_prev.so default scripts/bin/libtfQMRgpu_prev.so default
+    grep -v amdgpu.ids gpurun_out/r04af_one.txt >> gpurun_out/r04af_ab.txt
+  done
+  cat gpurun_out/r04af_ab.txt
+  step 600 r04af_tests.log python -m pytest tests/test_gpu_hash_mode.py tests/test_gpu_parity.py -q -x
+  tail -n 3 gpurun_out/r04af_tests.log
   ;;
 *) echo "unknown step $1"; exit 1;;
 esac

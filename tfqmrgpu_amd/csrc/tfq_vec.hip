@@ -270,24 +270,40 @@ __global__ __launch_bounds__(256) void k_x_v6_v7(DevPlan d) {
     Scal<R, LN, G::VEC> eta, eta2, alfa, c67, c67a;
     eta.load((R const*)d.eta, col, t, d.ilv); eta2.load((R const*)d.eta2, col, t, d.ilv); alfa.load((R const*)d.alfa, col, t, d.ilv);
     c67.load((R const*)d.c67, col, t, d.ilv); c67a.load((R const*)d.c67a, col, t, d.ilv);
+    // (r04) TWO items per trip with the loads of both in front of the arithmetic: a chunk of 16 KiB is exactly two trips of the 256 threads, and with one
+    //  item per trip the second trip's loads were issued behind the first trip's stores -- lab switch TFQMRGPU_VEC2, profiles/r04_vector_kernels.txt
     auto sweep = [&](auto first) __attribute__((always_inline)) {   // two loops, not a branch per trip (measured: 2.4 %)
-        for (uint32_t w = t; w < nItems; w += G::T) {
-            TFQ_ITEM_OFFSETS(G)
-            R sr[G::VEC], si[G::VEC], xr[G::VEC], xi[G::VEC], ar[G::VEC], ai[G::VEC], br[G::VEC], bi[G::VEC];
-            if constexpr (decltype(first)::value) {          // v7 = x = 0 at the start of a solve: not read (same arithmetic on zeros)
+        auto item_off = [&](uint32_t w, size_t& re, size_t& im) __attribute__((always_inline)) {
+            uint32_t const blk = w / G::IPB;
+            re = base + size_t(blk) * 2 * G::P + size_t(w - blk * G::IPB) * G::VEC; im = re + G::P;
+        };
+        for (uint32_t w0 = t; w0 < nItems; w0 += 2 * G::T) {
+            R sr[2][G::VEC], si[2][G::VEC], xr[2][G::VEC], xi[2][G::VEC], ar[2][G::VEC], ai[2][G::VEC], br[2][G::VEC], bi[2][G::VEC];
+            size_t re[2], im[2];
+            bool const two = (w0 + G::T < nItems);
+            item_off(w0, re[0], im[0]); item_off(two ? w0 + G::T : w0, re[1], im[1]);
 #pragma unroll
-                for (int v = 0; v < G::VEC; ++v) { sr[v] = 0; si[v] = 0; xr[v] = 0; xi[v] = 0; }
-            } else { ldv(sr, v7 + re); ldv(si, v7 + im); ldv(xr, x + re); ldv(xi, x + im); }
-            ldv(ar, v4 + re); ldv(ai, v4 + im); ldv(br, v6 + re); ldv(bi, v6 + im);
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !two) break;
+                if constexpr (decltype(first)::value) {          // v7 = x = 0 at the start of a solve: not read (same arithmetic on zeros)
 #pragma unroll
-            for (int v = 0; v < G::VEC; ++v) {
-                if (pend) axpy(xr[v], xi[v], sr[v], si[v], eta2.re[v], eta2.im[v]);  // x  += eta2 v7   (previous iteration)
-                xpay(sr[v], si[v], br[v], bi[v], c67a.re[v], c67a.im[v]);           // v7  = v6 + c67a v7
-                axpy(xr[v], xi[v], sr[v], si[v], eta.re[v], eta.im[v]);             // x  += eta  v7
-                axpy(br[v], bi[v], ar[v], ai[v], alfa.re[v], alfa.im[v]);           // v6 += alfa v4
-                xpay(sr[v], si[v], br[v], bi[v], c67.re[v], c67.im[v]);             // v7  = v6 + c67 v7
+                    for (int v = 0; v < G::VEC; ++v) { sr[u][v] = 0; si[u][v] = 0; xr[u][v] = 0; xi[u][v] = 0; }
+                } else { ldv(sr[u], v7 + re[u]); ldv(si[u], v7 + im[u]); ldv(xr[u], x + re[u]); ldv(xi[u], x + im[u]); }
+                ldv(ar[u], v4 + re[u]); ldv(ai[u], v4 + im[u]); ldv(br[u], v6 + re[u]); ldv(bi[u], v6 + im[u]);
             }
-            stv(x + re, xr); stv(x + im, xi); stv(v6 + re, br); stv(v6 + im, bi); stv(v7 + re, sr); stv(v7 + im, si);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !two) break;
+#pragma unroll
+                for (int v = 0; v < G::VEC; ++v) {
+                    if (pend) axpy(xr[u][v], xi[u][v], sr[u][v], si[u][v], eta2.re[v], eta2.im[v]);  // x  += eta2 v7   (previous iteration)
+                    xpay(sr[u][v], si[u][v], br[u][v], bi[u][v], c67a.re[v], c67a.im[v]);           // v7  = v6 + c67a v7
+                    axpy(xr[u][v], xi[u][v], sr[u][v], si[u][v], eta.re[v], eta.im[v]);             // x  += eta  v7
+                    axpy(br[u][v], bi[u][v], ar[u][v], ai[u][v], alfa.re[v], alfa.im[v]);           // v6 += alfa v4
+                    xpay(sr[u][v], si[u][v], br[u][v], bi[u][v], c67.re[v], c67.im[v]);             // v7  = v6 + c67 v7
+                }
+                stv(x + re[u], xr[u]); stv(x + im[u], xi[u]); stv(v6 + re[u], br[u]); stv(v6 + im[u], bi[u]); stv(v7 + re[u], sr[u]); stv(v7 + im[u], si[u]);
+            }
         }
     };
     if (d.first) sweep(std::true_type{}); else sweep(std::false_type{});
