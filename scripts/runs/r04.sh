@@ -279,5 +279,17 @@ af)
   step 600 r04af_tests.log python -m pytest tests/test_gpu_hash_mode.py tests/test_gpu_parity.py -q -x
   tail -n 3 gpurun_out/r04af_tests.log
   ;;
+ag)
+  # 8 x 9 and 8 x 10 z on the row-pair-interleaved order (k_spmm_ilv8w with a ragged second column group): the whole GPU suite, then lab ILV89 = 0 | 1
+  step 1100 r04ag_tests.log python -m pytest tests -q -x -m gpu
+  tail -n 3 gpurun_out/r04ag_tests.log
+  export AB_ALL=1
+  for wl in st:8:9:z:241:241:4 st:8:10:z:228:228:4; do
+    echo "## $wl" >> gpurun_out/r04ag_ab.txt
+    step 400 r04ag_one.txt python scripts/ab_fused.py $wl lab@TFQMRGPU_ILV89=0 lab@TFQMRGPU_ILV89=1 default
+    grep -v amdgpu.ids gpurun_out/r04ag_one.txt >> gpurun_out/r04ag_ab.txt
+  done
+  cat gpurun_out/r04ag_ab.txt
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac

@@ -247,6 +247,7 @@ tfqmrgpuStatus_t layoutBuffer(Plan& p, int LM, int LN, char precision) {
         int ilv = 0;
         if (ilvEnv && 'z' == prec && ((16 == LM && 16 == LN) || (8 == LM && 8 == LN && ilvEnv != 16))) ilv = 2;
         if ((1 == ilvEnv || 2 == ilvEnv) && 'z' == prec && 8 == LM && (32 == LN || 64 == LN)) ilv = 2;      // k_spmm_ilv8w (r03)
+        if (1 == ilvEnv && 'z' == prec && 8 == LM && (9 == LN || 10 == LN) && lab_switch("TFQMRGPU_ILV89", 1)) ilv = 2;   // k_spmm_ilv8w with a ragged second column group (r04)
         if ((1 == ilvEnv || 3 == ilvEnv) && 'c' == prec && 16 == LM && 16 == LN) ilv = 4;
         if (1 == ilvEnv && 'c' == prec && (16 == LM || 32 == LM) && 32 == LN) ilv = 4;   // 16 x 32, 32 x 32 (k_spmm_ilvf)
         if (1 == ilvEnv && 'c' == prec && 8 == LM && (8 == LN || 32 == LN || 64 == LN)) ilv = 4;   // k_spmm_ilv8f (r03)

@@ -1456,8 +1456,9 @@ template <int LN, int EPI, bool FIRST = false>   // FIRST: the launch of the fir
 __global__ __launch_bounds__(256) void k_spmm_ilv8w(SpmmArgs a) {
     if (gate_closed(a)) return;
     using R = double;
-    static_assert(LN % 8 == 0 && LN > 8, "groups of 8 block columns");
-    constexpr int NTB = LN / 8;                       // column groups of a block
+    static_assert(LN > 8 && (LN % 8 == 0 || LN < 16), "groups of 8 block columns, the last one of 8 x 9 | 8 x 10 ragged");
+    constexpr int NTB = (LN + 7) / 8;                 // column groups of a block
+    constexpr bool RAGGED = (LN % 8 != 0);            // (r04) 8 x 9, 8 x 10: the second group has 1 | 2 columns -- its other lanes load nothing, multiply zeros and store nothing
     constexpr int NT = (NTB > 4) ? 4 : NTB;           // column groups of one unit of work of a wave (8 x 64: a Y block is two units;
                                                       //  all 8 groups in one wave need 255-271 VGPRs = one wave per SIMD)
     constexpr int HALVES = NTB / NT;
@@ -1486,11 +1487,12 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8w(SpmmArgs a) {
     int const t0 = (wave % HALVES) * NT;                  // first column group of this wave's units
     // this lane's 16 bytes of column group t0 + t of an X-shaped block: plane cp, row pair lr, column 8 (t0 + t) + j
     auto mine = [&](int t) { return cp * P + (lr * LN + 8 * (t0 + t) + j) * 2; };
+    auto live = [&](int t) { return !RAGGED || 8 * (t0 + t) + j < LN; };      // this lane's column of group t exists
     auto fetch = [&](Ops& o, uint32_t q) __attribute__((always_inline)) {
         o.av = *(d2v const*)(A0 + size_t(pairs[2 * size_t(q)]) * 2 * PA);
         R const* Xb = (R const*)a.X + size_t(pairs[2 * size_t(q) + 1]) * 2 * P;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) o.xv[t] = *(d2v const*)(Xb + mine(t));
+        for (int t = 0; t < NT; ++t) o.xv[t] = live(t) ? *(d2v const*)(Xb + mine(t)) : d2v{0, 0};
     };
     for (uint32_t u = wave; u < (last - first) * HALVES; u += 4) {
         uint32_t const y = first + u / HALVES;
@@ -1505,6 +1507,24 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8w(SpmmArgs a) {
                 acc[t] = Acc<R>::mma(o.av[1], o.xv[t][1], acc[t]);
             }
         };
+        // (r04) with at most two column groups per wave (8 x 9, 8 x 10) the epilogue operands are requested in FRONT of the block products, as k_spmm_ilv8 does:
+        // 20 registers; with four groups they are not (the accumulators of four groups are 32, the operand sets 40 registers)
+        constexpr bool PRE = UPD && (NT <= 2);
+        size_t const yb = size_t(y) * 2 * P;
+        d2v uP[PRE ? NT : 1], vP[PRE ? NT : 1]; f2v wP[PRE ? NT : 1];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                uP[t] = d2v{0, 0}; vP[t] = d2v{0, 0}; wP[t] = f2v{0, 0};
+                if (live(t)) {
+                    if constexpr (!(EPI == EPI_XPAY_DOT && FIRST)) {
+                        uP[t] = ld_stream<!RAGGED>((d2v const*)((R const*)a.e0 + yb + mine(t)));
+                        if constexpr (EPI == EPI_XPAY_DOT) vP[t] = ld_stream<!RAGGED>((d2v const*)((R const*)a.e1 + yb + mine(t)));
+                    }
+                    wP[t] = ld_stream<!RAGGED>((f2v const*)(a.v3 + yb + mine(t)));
+                }
+            }
+        }
         Ops o0, o1;
         if (q0 < q1) fetch(o0, q0);
         if (q0 + 1 < q1) fetch(o1, q0 + 1);
@@ -1519,24 +1539,27 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8w(SpmmArgs a) {
 
         uint32_t bq = 0xffffffffu;
         if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX ? a.bOfX[y] : y;
-        size_t const yb = size_t(y) * 2 * P;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             size_t const yoff = yb + mine(t);
+            bool const on = live(t);
             // lanes of plane 0 hold (Q00, Q10), lanes of plane 1 (Q01, Q11), rows 2 lr and 2 lr + 1: Re Y = Q00 - Q11, Im Y = Q01 + Q10
             d2v const qa = d2v{acc[t][0], acc[t][1]}, qb = xor8(d2v{acc[t][2], acc[t][3]});
             d2v const yM = cp ? d2v{qa[0] + qb[0], qa[1] + qb[1]} : d2v{qa[0] - qb[0], qa[1] - qb[1]};   // this lane's plane of Y
             d2v const yO = xor8(yM);
             d2v const yr = cp ? yO : yM, yi = cp ? yM : yO;
             if constexpr (UPD) {
-                R const srt = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + 8 * (t0 + t) + j];
-                R const sit = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + 8 * (t0 + t) + j];
-                d2v uM = d2v{0, 0}, vM = d2v{0, 0};
-                if constexpr (!(EPI == EPI_XPAY_DOT && FIRST)) {   // (first iteration of a solve: old v4 = v8 = 0, not read)
-                    uM = __builtin_nontemporal_load((d2v const*)((R const*)a.e0 + yoff));
-                    if constexpr (EPI == EPI_XPAY_DOT) vM = __builtin_nontemporal_load((d2v const*)((R const*)a.e1 + yoff));
+                R const srt = on ? ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + 8 * (t0 + t) + j] : R(0);
+                R const sit = on ? ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + 8 * (t0 + t) + j] : R(0);
+                d2v uM = d2v{0, 0}, vM = d2v{0, 0}; f2v wM = f2v{0, 0};
+                if constexpr (PRE) { uM = uP[t]; vM = vP[t]; wM = wP[t]; }
+                else {
+                    if constexpr (!(EPI == EPI_XPAY_DOT && FIRST)) {   // (first iteration of a solve: old v4 = v8 = 0, not read)
+                        if (on) uM = ld_stream<!RAGGED>((d2v const*)((R const*)a.e0 + yoff));
+                        if constexpr (EPI == EPI_XPAY_DOT) if (on) vM = ld_stream<!RAGGED>((d2v const*)((R const*)a.e1 + yoff));
+                    }
+                    if (on) wM = ld_stream<!RAGGED>((f2v const*)(a.v3 + yoff));
                 }
-                f2v const wM = __builtin_nontemporal_load((f2v const*)(a.v3 + yoff));
                 d2v const uO = xor8(uM), ur = cp ? uO : uM, ui = cp ? uM : uO;
                 f2v const wO = f2v{__shfl_xor(wM[0], 8), __shfl_xor(wM[1], 8)};
                 d2v const w0 = cp ? d2v{wO[0], wO[1]} : d2v{wM[0], wM[1]}, w1 = cp ? d2v{wM[0], wM[1]} : d2v{wO[0], wO[1]};
@@ -1564,11 +1587,13 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8w(SpmmArgs a) {
                     part[1][t] = __builtin_fma(di, w0[e], __builtin_fma(dr, w1[e], part[1][t]));
                     if constexpr (EPI == EPI_AXPY_NRM_DOT) part[2][t] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[2][t]));
                 }
-                __builtin_nontemporal_store(yM, (d2v*)((R*)a.Y + yoff));
-                __builtin_nontemporal_store(cp ? ni : nr, (d2v*)((R*)a.e0 + yoff));
+                if (on) {
+                    st_stream<!RAGGED>((d2v*)((R*)a.Y + yoff), yM);
+                    st_stream<!RAGGED>((d2v*)((R*)a.e0 + yoff), cp ? ni : nr);
+                }
             } else if constexpr (EPI == EPI_RESIDUAL) {       // |A x - b|^2, nothing stored (tfqmrgpu_core.hxx:265-269)
                 d2v bM = d2v{0, 0};
-                if (bq != 0xffffffffu) bM = *(d2v const*)((R const*)a.B + size_t(bq) * 2 * P + mine(t));
+                if (bq != 0xffffffffu && on) bM = *(d2v const*)((R const*)a.B + size_t(bq) * 2 * P + mine(t));
                 d2v const bO = xor8(bM), br = cp ? bO : bM, bi = cp ? bM : bO;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
@@ -1576,7 +1601,7 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8w(SpmmArgs a) {
                     part[0][t] = __builtin_fma(di, di, __builtin_fma(dr, dr, part[0][t]));
                 }
             } else {
-                __builtin_nontemporal_store(yM, (d2v*)((R*)a.Y + yoff));
+                if (on) st_stream<!RAGGED>((d2v*)((R*)a.Y + yoff), yM);
             }
         }
     }
@@ -1589,7 +1614,7 @@ __global__ __launch_bounds__(256) void k_spmm_ilv8w(SpmmArgs a) {
                 double v = part[p][t];
                 v += __shfl_xor(v, 16);
                 v += __shfl_xor(v, 32);
-                if (lane < 8) s[wave][p][8 * (t0 + t) + lane] = v;
+                if (lane < 8 && (!RAGGED || 8 * (t0 + t) + lane < LN)) s[wave][p][8 * (t0 + t) + lane] = v;
             }
         __syncthreads();
         for (int e = threadIdx.x; e < NPL * LN; e += 256) {
@@ -2091,7 +2116,7 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
             return;
         }
     }
-    if constexpr (LM == 8 && (LN == 32 || LN == 64) && sizeof(R) == 8) {
+    if constexpr (LM == 8 && (LN == 32 || LN == 64 || LN == 9 || LN == 10) && sizeof(R) == 8) {
         if (a.ilv && a.chunkFirst) {   // row pairs interleaved (tfq_plan.cpp: layoutBuffer)
             constexpr bool canFirst = (EPI == EPI_XPAY_DOT);
             if (canFirst && a.first) k_spmm_ilv8w<LN, EPI, canFirst><<<dim3(nWG), dim3(256), 0, s>>>(a);
@@ -2222,7 +2247,7 @@ char const* spmm_kernel_family(DevPlan const& d) {
     if (!z && LM % 16 == 0 && (32 == LN || 64 == LN) && 4 == d.ilv) return "k_spmm_ilvf";
     if (8 == LM && 8 == LN && z && d.ilv) return batched(d) ? "k_spmm_ilv8b" : "k_spmm_ilv8";
     if (8 == LM && (8 == LN || 32 == LN || 64 == LN) && !z && 4 == d.ilv) return "k_spmm_ilv8f";
-    if (8 == LM && (32 == LN || 64 == LN) && z && d.ilv) return "k_spmm_ilv8w";
+    if (8 == LM && (32 == LN || 64 == LN || 9 == LN || 10 == LN) && z && d.ilv) return "k_spmm_ilv8w";
     if (LM % 16 == 0 && LN % 16 == 0) return "k_spmm_mfma";
     if (8 == LM || (4 == LM && z && 32 == LN)) return "k_spmm_mfma8";
     if (4 == LM) return "k_spmm_small4";

@@ -26,10 +26,12 @@ template <typename R> struct Vec;
 template <> struct Vec<double> { static constexpr int N = 2; using T = double2; };
 template <> struct Vec<float>  { static constexpr int N = 4; using T = float4;  };
 
-// largest thread count <= 256 such that a thread's elements keep their RHS index j on every trip
+// largest thread count <= 256 such that a thread's elements keep their RHS index j on every trip -- in the native order ((t * VEC) % LN == 0) and in
+// the interleaved ones, where a thread's VEC elements are ROWS of one column and its column is (t + trip * T) % LN: T % LN == 0 (r04, for the 8 x 9 and
+// 8 x 10 plans on row pairs; the only shape for which the two rules differ is LN = 10: 250 threads where 255 would do for the native order)
 template <int LN, int VEC> constexpr int activeThreads() {
     int t = 256;
-    while ((t * VEC) % LN) --t;
+    while (t % LN) --t;
     return t;
 }
 
