@@ -291,5 +291,14 @@ ag)
   done
   cat gpurun_out/r04ag_ab.txt
   ;;
+ah)
+  # soak: the fence-free hand-overs (folded column operations, segment shares of long columns) must never change a bit -- N solves per workload, one status / iteration count / residual / md5 of X
+  for spec in "fd2d_16x16_z_small 400" "st:16:16:z:16:16:4 400" "st:8:8:z:24:24:2 400" "stencil3d_32x32_c 300" "stencil2d_8x8_z 60" "st:16:16:z:128:128:4 60" "fd2d_16x16_z 30" "fd2d_16x16_z_small 200 m" "st:8:9:z:60:60:3 200"; do
+    set -- $spec
+    step 500 r04ah_one.txt python scripts/soak.py "$@"
+    tail -n 1 gpurun_out/r04ah_one.txt >> gpurun_out/r04ah_soak.txt
+  done
+  cat gpurun_out/r04ah_soak.txt
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac
