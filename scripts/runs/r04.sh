@@ -300,5 +300,10 @@ ah)
   done
   cat gpurun_out/r04ah_soak.txt
   ;;
+ai)
+  # all 15 block shapes x z, c at the end of the round (scripts/shape_survey.sh)
+  step 1100 r04ai_shape_survey.txt bash scripts/shape_survey.sh
+  grep -v amdgpu.ids gpurun_out/r04ai_shape_survey.txt | cut -c1-260
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac
