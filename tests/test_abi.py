@@ -302,3 +302,22 @@ def test_kept_profiler_figures_name_their_kernel():
         assert e.get("_kernel", "").startswith("k_spmm_") and e.get("_sha") and e.get("_round"), wl
         assert e["_kernels"].get("spmm_v4_dot", "").startswith(e["_kernel"] + "<"), wl
         assert all(isinstance(v, int) and v > 0 for k, v in e.items() if not k.startswith("_")), wl
+
+
+def test_round4_extensions_refuse_what_they_cannot_do():
+    """The additive calls of round 4 on the host side (no device call is reached): the kernel-family getter needs a registered buffer, the prepared
+    launch order of the stand-alone multiply needs its lists, a null order is released as what it is."""
+    pr = PR.stencil_2d(4, 3, 16, 16, 2, seed=3)
+    s = T.Solver()
+    s.create_plan(pr)
+    s.buffer_size(16, 16, "z")
+    buf = C.create_string_buffer(64)
+    assert T.decode(T.lib.tfqmrgpuExt_getMultiplyKernel(s.plan, buf, 64))[0] == 7          # no buffer yet: TFQMRGPU_POINTER_INVALID
+    assert T.decode(T.lib.tfqmrgpuExt_getMultiplyKernel(s.plan, None, 64))[0] == 7
+    assert T.decode(T.lib.tfqmrgpuExt_getMultiplyKernel(None, buf, 64))[0] == 7
+    order = C.c_void_p(None)
+    assert T.decode(T.lib.tfqmrgpuExt_multiplyPrepare(s.handle, b"z", 16, 16, 10, None, None, 4, C.byref(order)))[0] == 7
+    assert T.decode(T.lib.tfqmrgpuExt_multiplyPrepare(s.handle, b"z", 16, 16, 10, None, None, 4, None))[0] == 7
+    assert T.lib.tfqmrgpuExt_multiplyRelease(None) == 0
+    assert T.decode(T.lib.tfqmrgpuExt_multiplyOrdered(s.handle, b"z", 16, 16, 10, None, None, None, None, None, None))[0] == 7
+    s.close()
