@@ -305,5 +305,14 @@ ai)
   step 1100 r04ai_shape_survey.txt bash scripts/shape_survey.sh
   grep -v amdgpu.ids gpurun_out/r04ai_shape_survey.txt | cut -c1-260
   ;;
+aj)
+  # launch order along the strongest band coupling (lab: TFQMRGPU_ORDER=2) x column-group size, on config 5, P2, config 3 and the config-4 shard
+  for wl in stencil2d_8x8_z fd2d_16x16_z stencil3d_32x32_c st:16:16:z:128:128:32; do
+    echo "## $wl" >> gpurun_out/r04aj_ab.txt
+    step 600 r04aj_one.txt python scripts/ab_fused.py $wl lab@TFQMRGPU_ORDER=1 lab@TFQMRGPU_ORDER=2 lab@TFQMRGPU_ORDER=2,TFQMRGPU_ORDER_G=8 lab@TFQMRGPU_ORDER=2,TFQMRGPU_ORDER_G=16
+    grep -v amdgpu.ids gpurun_out/r04aj_one.txt >> gpurun_out/r04aj_ab.txt
+  done
+  cat gpurun_out/r04aj_ab.txt
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac
