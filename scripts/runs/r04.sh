@@ -314,5 +314,23 @@ aj)
   done
   cat gpurun_out/r04aj_ab.txt
   ;;
+ak)
+  # column operations with their per-RHS scalars requested in front of the column's sum: previous commit | this one, every class; then the tests that hold the bits
+  export AB_ALL=1
+  for wl in stencil3d_32x32_c fd2d_16x16_z "FD:6,24,4,2,-0.25,4"; do
+    echo "## $wl" >> gpurun_out/r04ak_ab.txt
+    if [ "${wl#FD:}" != "$wl" ]; then
+      for lib in scripts/bin/libtfQMRgpu_prev.so tfqmrgpu_amd/lib/libtfQMRgpu.so scripts/bin/libtfQMRgpu_prev.so tfqmrgpu_amd/lib/libtfQMRgpu.so; do
+        TFQMRGPU_LIB=$GRAFT_REPO_ROOT/$lib python scripts/fold_crossover.py "$wl" 2>&1 | grep -v amdgpu.ids | grep "fold_max 0 " | sed -e "s|^|$lib |" >> gpurun_out/r04ak_ab.txt
+      done
+    else
+      step 400 r04ak_one.txt python scripts/ab_fused.py $wl scripts/bin/libtfQMRgpu_prev.so default scripts/bin/libtfQMRgpu_prev.so default
+      grep -v amdgpu.ids gpurun_out/r04ak_one.txt >> gpurun_out/r04ak_ab.txt
+    fi
+  done
+  cat gpurun_out/r04ak_ab.txt
+  step 900 r04ak_tests.log python -m pytest tests/test_gpu_hash_mode.py tests/test_gpu_parity.py tests/test_gpu_mixed.py -q -x
+  tail -n 3 gpurun_out/r04ak_tests.log
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac

@@ -151,13 +151,15 @@ __device__ inline bool column_total(DevPlan const& d, double const* part, uint32
 // dec35: beta = z/rho, rho = z  (tfqmrgpu_linalg.hxx:50-75)
 template <typename R, int LN>
 __device__ inline void col_dec35(DevPlan const& d, uint32_t const col, double* s, int seg, int* lastFlag) {
-    double z[2];
-    if (!column_total<LN, 2>(d, d.pz, col, seg, s, lastFlag, z)) return;
-    int const j = threadIdx.x;
-    if (j >= LN) return;
-    size_t const ir = (size_t(col) * 2 + 0) * LN + j, ii = ir + LN;
+    // (r04: the per-RHS scalars of the update are requested in FRONT of the column's sum -- they do not depend on it, and behind it each of them was one more
+    //  round trip to memory in a kernel that is nothing but round trips; lanes beyond LN read the last right-hand side's, harmlessly)
+    int const j = threadIdx.x, jc = (j < LN) ? j : LN - 1;
+    size_t const ir = (size_t(col) * 2 + 0) * LN + jc, ii = ir + LN;
     R* rho = (R*)d.rho; R* bet = (R*)d.beta;
     double const rr = double(rho[ir]), ri = double(rho[ii]);
+    double z[2];
+    if (!column_total<LN, 2>(d, d.pz, col, seg, s, lastFlag, z)) return;
+    if (j >= LN) return;
     double const abs2rho = rr * rr + ri * ri, abs2z = z[0] * z[0] + z[1] * z[1];
     d.z[ir] = z[0]; d.z[ii] = z[1];
     if (abs2z < TFQ_EPS || abs2rho < TFQ_EPS) {
@@ -174,25 +176,25 @@ __device__ inline void col_dec35(DevPlan const& d, uint32_t const col, double* s
 // dec34: alfa = -rho/z, c67 = z*(var*eta/rho)  (tfqmrgpu_linalg.hxx:116-151)
 template <typename R, int LN>
 __device__ inline void col_dec34(DevPlan const& d, uint32_t const col, double* s, int seg, int* lastFlag) {
-    double z[2];
-    if (!column_total<LN, 2>(d, d.pz, col, seg, s, lastFlag, z)) return;
-    int const j = threadIdx.x;
-    if (j >= LN) return;
-    size_t const ir = (size_t(col) * 2 + 0) * LN + j, ii = ir + LN;
+    int const j = threadIdx.x, jc = (j < LN) ? j : LN - 1;
+    size_t const ir = (size_t(col) * 2 + 0) * LN + jc, ii = ir + LN;
     // the latest eta is the one of the second half step of the previous iteration (eta2)
     R const* rho = (R const*)d.rho; R const* eta = (R const*)d.eta2; R* alf = (R*)d.alfa; R* c67 = (R*)d.c67a;
-    double const rr = double(rho[ir]), ri = double(rho[ii]);
+    double const rr = double(rho[ir]), ri = double(rho[ii]);                     // (requested in front of the column's sum, like everything it does not depend on)
+    double const er = double(eta[ir]), ei = double(eta[ii]), var0 = d.var[size_t(col) * LN + jc];
+    double z[2];
+    if (!column_total<LN, 2>(d, d.pz, col, seg, s, lastFlag, z)) return;
+    if (j >= LN) return;
     double const abs2rho = rr * rr + ri * ri, abs2z = z[0] * z[0] + z[1] * z[1];
     d.z[ir] = z[0]; d.z[ii] = z[1];
     if (abs2z < TFQ_EPS || abs2rho < TFQ_EPS) {
         d.status[size_t(col) * LN + j] = -2;
         alf[ir] = 0; alf[ii] = 0; c67[ir] = 0; c67[ii] = 0;
     } else {
-        double const er = double(eta[ir]), ei = double(eta[ii]);
         double const zden = -1. / abs2z;
         alf[ir] = R((rr * z[0] + ri * z[1]) * zden);
         alf[ii] = R((ri * z[0] - rr * z[1]) * zden);
-        double const vden = d.var[size_t(col) * LN + j] / abs2rho;
+        double const vden = var0 / abs2rho;
         double const tr = (er * rr + ei * ri) * vden, ti = (ei * rr - er * ri) * vden;
         c67[ir] = R(z[0] * tr - z[1] * ti);
         c67[ii] = R(z[1] * tr + z[0] * ti);
@@ -204,15 +206,19 @@ __device__ inline void col_dec34(DevPlan const& d, uint32_t const col, double* s
 //   colrec[col] = { max_j tau_j/|b_j|^2 , 1 if any RHS of the column is not broken down (-1/-2) }
 template <typename R, int LN, bool SETC67, bool FINAL>
 __device__ inline void col_decT(DevPlan const& d, uint32_t const col, double* s, double (*rec)[64], int seg, int* lastFlag) {
+    int const j = threadIdx.x, jc = (j < LN) ? j : LN - 1;
+    double const Tau0 = d.tau[size_t(col) * LN + jc];                           // (requested in front of the column's sum, like everything it does not depend on)
+    int8_t const st0 = d.status[size_t(col) * LN + jc];
+    R const alr0 = ((R const*)d.alfa)[(size_t(col) * 2 + 0) * LN + jc], ali0 = ((R const*)d.alfa)[(size_t(col) * 2 + 1) * LN + jc];
+    double const invB0 = FINAL ? d.invBn2[size_t(col) * LN + jc] : 0.;
     double dd[1];
     if (!column_total<LN, 1>(d, d.pd, col, seg, s, lastFlag, dd)) return;
-    int const j = threadIdx.x;
     if (j < LN) {
         size_t const ir = (size_t(col) * 2 + 0) * LN + j, ii = ir + LN, i1 = size_t(col) * LN + j;
-        R const* alf = (R const*)d.alfa; R* eta = (R*)(FINAL ? d.eta2 : d.eta); R* c67 = (R*)d.c67;
+        R* eta = (R*)(FINAL ? d.eta2 : d.eta); R* c67 = (R*)d.c67;
         double cosi = 0; R r67 = 1;
-        double const Tau = d.tau[i1];
-        int8_t st = d.status[i1];
+        double const Tau = Tau0;
+        int8_t st = st0;
         double newTau;
         if (fabs(Tau) > TFQ_EPS) {
             double const Var = dd[0] / Tau;
@@ -227,9 +233,9 @@ __device__ inline void col_decT(DevPlan const& d, uint32_t const col, double* s,
         d.tau[i1] = newTau;
         d.d[i1] = dd[0];
         if (st < 0) { eta[ir] = 0; eta[ii] = 0; }
-        else { eta[ir] = R(-cosi * alf[ir]); eta[ii] = R(-cosi * alf[ii]); }
+        else { eta[ir] = R(-cosi * alr0); eta[ii] = R(-cosi * ali0); }
         if (SETC67) { c67[ir] = r67; c67[ii] = 0; }
-        if (FINAL) { rec[0][j] = newTau * d.invBn2[i1]; rec[1][j] = (st == -1 || st == -2) ? 0. : 1.; }
+        if (FINAL) { rec[0][j] = newTau * invB0; rec[1][j] = (st == -1 || st == -2) ? 0. : 1.; }
     }
     if (FINAL) {
         __syncthreads();
