@@ -52,8 +52,9 @@ def build_problem(name, rank, world=1):
         pr = PR.stencil_2d(256, 256, 8, 8, 8, seed=5)
         prec, desc = "z", "5-point block stencil 256x256, 8x8 complex<double>, 8 block columns"
     elif name.startswith("st:"):        # st:LM:LN:prec:nx:ny:ncols  (5-point block stencil, X dense in ncols block columns)
-        _, lm, ln, prec, nx, ny, nc = name.split(":")
-        pr = PR.stencil_2d(int(nx), int(ny), int(lm), int(ln), int(nc), seed=7)
+        _, lm, ln, prec, nx, ny, nc = name.split(":")[:7]
+        points = int(name.split(":")[7]) if name.count(":") > 6 else 5      # st:...:13 = the 13-point stencil
+        pr = PR.stencil_2d(int(nx), int(ny), int(lm), int(ln), int(nc), seed=7, points=points)
         if prec == "c":
             pr.tolerance = 1e-4
         desc = "5-point block stencil %sx%s, %sx%s complex<%s>, %s block columns" % (nx, ny, lm, ln, "double" if prec == "z" else "float", nc)

@@ -332,5 +332,39 @@ ak)
   step 900 r04ak_tests.log python -m pytest tests/test_gpu_hash_mode.py tests/test_gpu_parity.py tests/test_gpu_mixed.py -q -x
   tail -n 3 gpurun_out/r04ak_tests.log
   ;;
+al)
+  # k_spmm_small4 with three 20-lane thread groups per wave for 4 x 5 blocks (two 32-lane groups before): previous commit | this one, z and c; 4 x 4 as the control
+  export AB_ALL=1
+  for wl in st:4:5:z:457:457:4 st:4:5:c:647:647:4 st:4:4:z:512:512:4; do
+    echo "## $wl" >> gpurun_out/r04al_ab.txt
+    step 400 r04al_one.txt python scripts/ab_fused.py $wl scripts/bin/libtfQMRgpu_prev.so default scripts/bin/libtfQMRgpu_prev.so default
+    grep -v amdgpu.ids gpurun_out/r04al_one.txt >> gpurun_out/r04al_ab.txt
+  done
+  cat gpurun_out/r04al_ab.txt
+  step 900 r04al_tests.log python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py tests/test_gpu_operator.py tests/test_gpu_mixed.py -q -x
+  tail -n 3 gpurun_out/r04al_tests.log
+  ;;
+am)
+  # k_spmm_m4 (v_mfma_f64_4x4x4_4b_f64, chunk index data in LDS) against k_spmm_small4 on 4 x 4 and 4 x 8 z: lab switch TFQMRGPU_M4 = 0 | 1 on one build
+  step 900 r04am_tests.log python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py tests/test_gpu_operator.py -q -x
+  tail -n 3 gpurun_out/r04am_tests.log
+  export AB_ALL=1
+  for wl in st:4:4:z:512:512:4 st:4:8:z:362:362:4; do
+    echo "## $wl" >> gpurun_out/r04am_ab.txt
+    step 400 r04am_one.txt python scripts/ab_fused.py $wl lab@TFQMRGPU_M4=0 lab@TFQMRGPU_M4=1 lab@TFQMRGPU_M4=0 lab@TFQMRGPU_M4=1
+    grep -v amdgpu.ids gpurun_out/r04am_one.txt >> gpurun_out/r04am_ab.txt
+  done
+  cat gpurun_out/r04am_ab.txt
+  ;;
+an)
+  # k_spmm_m4: products requested per trip (TFQ_M4_NB = 4 | 5 | 6 | 8 = default), 5-point and 13-point stencils
+  export AB_ALL=1
+  for wl in st:4:4:z:512:512:4 st:4:8:z:362:362:4 st:4:4:z:512:512:4:13; do
+    echo "## $wl" >> gpurun_out/r04an_ab.txt
+    step 400 r04an_one.txt python scripts/ab_fused.py $wl scripts/bin/libtfQMRgpu_nb4.so scripts/bin/libtfQMRgpu_nb5.so scripts/bin/libtfQMRgpu_nb6.so default
+    grep -v amdgpu.ids gpurun_out/r04an_one.txt | grep -v "^    " >> gpurun_out/r04an_ab.txt
+  done
+  cat gpurun_out/r04an_ab.txt
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac

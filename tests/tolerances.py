@@ -18,7 +18,8 @@ Z_TOL = {
     "dense_random":      dict(hist=3e-10, half=2e-12, res=5e-6),    # 1.1e-10 / 6.8e-13 / 2.3e-6
     "stencil_8x8":       dict(hist=1e-11, half=1e-12, res=2e-6),    # 9.5e-13 / 1.7e-13 / 1.0e-6
     "stencil_8x32":      dict(hist=1e-10, half=1e-12, res=3e-7),    # 4.3e-11 / 2.6e-13 / 1.3e-7
-    "dense_random_rect": dict(hist=1e-10, half=1e-12, res=8e-6),    # 4.5e-11 / 2.4e-13 / 3.7e-6 (residual 2e-11: noise floor)
+    "dense_random_rect": dict(hist=1e-9,  half=1e-12, res=8e-6),    # 4.5e-10 / 2.4e-13 / 3.7e-6 (residual 2e-11: noise floor; r04, k_spmm_m4 --
+                                                                    # one running MFMA sum over the products of a Y block: hist 4.5e-11 -> 4.5e-10 in the LAST entry, 1.2e-20)
     "fd_4x4_2d":         dict(hist=2e-5,  half=1e-10, res=8e-5),    # 9.2e-6  / 2.0e-11 / 3.8e-5
     "fd_8x8_3d":         dict(hist=1.7,   half=1.4e-7, res=0.52),   # 8.5e-1  / 7.0e-8  / 2.6e-1 (both below the threshold)
     "julia_kat":         dict(hist=1.3,   half=1e-14, res=0.5),     # 6.5e-1  / 2.2e-15 / 2.4e-1 (converges to 5e-15)

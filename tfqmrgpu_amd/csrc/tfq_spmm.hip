@@ -23,6 +23,7 @@
 //    instances recompute the shadow vector from its hash instead of reading it (HASH).
 //  * k_spmm_mfma8 : LM == 8 (and 4 x 32 z): [Re A; Im A] x [Re X | Im X] fills one 16 x 16 tile per 8 block columns (LN = 9,
 //    10: the last tile is masked; LM == 4: half of the rows are empty -- the matrix pipe is idle in these HBM-bound shapes).
+//  * k_spmm_m4     : 4 x 4 and 4 x 8 in double: four 4 x 4 x 4 products per v_mfma_f64_4x4x4_4b_f64, one element per lane, no LDS.
 //  * k_spmm_small4 : the other 4-row shapes: one lane per element, operands once per thread group through LDS.
 //  * k_spmm_direct : one thread per output element; only as the epilogue of a user-defined operator,
 //    operands through the vector L1.
@@ -1939,7 +1940,7 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // 4-row blocks that are too small for the tile kernel (4 x 4, and the float 4-row shapes: a block is 128 ... 1024 bytes).
-// A thread group of 16, 32 or 64 lanes owns one sub-block of 4 x min(LN, 16) elements, one element per lane; the operands
+// A thread group of 16, 20, 32 or 64 lanes owns one sub-block of 4 x min(LN, 16) elements, one element per lane; the operands
 // of a block product are read ONCE per group (4 memory instructions per wave and product instead of 16 per lane in
 // k_spmm_direct), pass through a group-private LDS patch and are broadcast from there.  Groups never straddle a wave and
 // LDS operations of one wave complete in order, so no barrier is needed inside the product loop.
@@ -1950,14 +1951,15 @@ __global__ __launch_bounds__(256) void k_spmm_small4(SpmmArgs a) {
     constexpr int LNS = (LN > 16) ? 16 : LN;             // columns of a sub-block
     constexpr int NSUB = LN / LNS;                       // sub-blocks per block (LN = 32: 2)
     constexpr int PE = LM * LNS;                         // elements of a sub-block: 16, 20, 32, 64
-    constexpr int PG = (PE <= 16) ? 16 : (PE <= 32) ? 32 : 64;   // lanes of a thread group
-    constexpr int NG = 256 / PG;                         // thread groups per work group
+    constexpr int GPW = 64 / PE;                         // thread groups per wave, PE lanes each: 4, 3 (4 x 5: lanes 60..63 idle), 2, 1
+    constexpr int NG = 4 * GPW;                          // thread groups per work group
     constexpr int NPL = EpiPlanes<EPI>::N;
     static_assert(LN % LNS == 0 && NG % NSUB == 0, "a thread group keeps its sub-block index");
     __shared__ R As[NG][2][LM * LM];
     __shared__ R Xs[NG][2][PE];
-    int const t = threadIdx.x, g = t / PG, e = t % PG;
-    bool const valid = (e < PE);
+    int const t = threadIdx.x, wv = t >> 6, ln = t & 63;
+    bool const valid = (ln < GPW * PE);
+    int const g = wv * GPW + (valid ? ln / PE : GPW - 1), e = valid ? ln % PE : PE;   // idle lanes walk with the wave's last group and touch nothing
     int const i = valid ? e / LNS : 0, jj = valid ? e % LNS : 0;
     int const j = (g % NSUB) * LNS + jj;                 // block column of this lane
     uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;   // XCD-aware launch order (tfq_plan.cpp)
@@ -2022,12 +2024,142 @@ __global__ __launch_bounds__(256) void k_spmm_small4(SpmmArgs a) {
             //  134 VGPRs for k_spmm_small4<., 4, EPI_AXPY_NRM_DOT> against 76 for its siblings, half the waves per SIMD; r03)
 #pragma unroll 1
             for (int gg = jx / LNS; gg < NG; gg += NSUB)
-                for (int r = 0; r < LM; ++r) sum += red[p][gg * PG + r * LNS + jx % LNS];
+                for (int r = 0; r < LM; ++r) sum += red[p][(gg / GPW) * 64 + (gg % GPW) * PE + r * LNS + jx % LNS];
             write_record<EPI>(a, chunk, LN, p, jx, sum);
         }
         if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
     }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// 4 x 4 and 4 x 8 blocks in double: four 4 x 4 x 4 products per v_mfma_f64_4x4x4_4b_f64.  The instruction keeps its four
+// blocks interleaved at 4 lanes (measured with one-hot operands, scripts/mfma4_probe.hip): with lo = lane % 4,
+// b = lane / 4 % 4, hi = lane / 16 a lane holds  A_b[i = lo][k = hi],  B_b[k = hi][j = lo]  and receives  D_b[i = hi][j = lo].
+// A blocks are stored as [k][i] and X, Y blocks as [i][j], so every lane loads and stores ONE element per plane at
+// hi * 4 + lo (A) or hi * LN + column quad + lo (X, Y): no LDS patch, no broadcast -- k_spmm_small4 spends 25 LDS
+// instructions per Y block on them.  A slot (b of a wave, 16 per work group) walks over Y sub-blocks of 4 x 4; the four
+// slots of a wave step together, a slot that has run out of products feeds zeros.
+#ifndef TFQ_M4_NB
+#define TFQ_M4_NB 8
+#endif
+template <int LN, int EPI>
+__global__ __launch_bounds__(256) void k_spmm_m4(SpmmArgs a) {
+    using R = double;
+    if (gate_closed(a)) return;
+    constexpr int LM = 4, P = LM * LN, NSUB = LN / 4, NS = 16, NB = TFQ_M4_NB;
+    constexpr int NPL = EpiPlanes<EPI>::N;
+    static_assert(LN % 4 == 0 && NS % NSUB == 0, "a slot keeps its column quad");
+    int const t = threadIdx.x, wv = t >> 6, lane = t & 63;
+    int const lo = lane & 3, b = (lane >> 2) & 3, hi = lane >> 4;
+    int const slot = wv * 4 + b;
+    int const j = (slot % NSUB) * 4 + lo;                // block column of this lane (X and Y)
+    int const ea = hi * LM + lo, ex = hi * LN + j;       // this lane's element of an A block, of an X or Y block
+    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;   // XCD-aware launch order (tfq_plan.cpp)
+    uint32_t first, last, col = 0;
+    if (a.chunkFirst) { first = a.chunkFirst[chunk]; last = a.chunkFirst[chunk + 1]; col = a.chunkCol[chunk]; }
+    else { first = chunk * a.CH; last = min(first + a.CH, a.nY); }
+
+    R sr = 0, si = 0;
+    if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
+        sr = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + j];
+        si = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + j];
+    }
+    double part[NPL > 0 ? NPL : 1] = {};
+
+    // An item = a 4 x 4 sub-block of a Y block (item % NSUB == slot % NSUB); slot s takes items s, s + 16, ...  Three dependent
+    // requests lead to a product (row range -> index pairs -> operands).  The work group fetches the row ranges and the index
+    // pairs of its whole chunk into LDS first (two latencies, once), so that a trip -- up to NB products of four items per
+    // wave -- waits for ONE memory latency; k_spmm_small4 waits for two per product.
+    constexpr uint32_t kRows = 256, kPairs = 1024;       // LDS patch: chunks of at most 256 Y blocks (tfq_plan.cpp: 16 KiB of 256-byte blocks = 64)
+    __shared__ uint32_t sStarts[kRows + 1];
+    __shared__ uint32_t sPairs[2 * kPairs];
+    uint32_t const nRows = last - first, nItems = nRows * NSUB;
+    uint32_t const qBase = a.starts[first], qEnd = a.starts[last];      // (uniform: scalar loads)
+    bool const inLds = (nRows <= kRows) && (qEnd - qBase <= kPairs);
+    if (inLds) {
+        for (uint32_t i = t; i <= nRows; i += 256) sStarts[i] = a.starts[first + i];
+        for (uint32_t i = t; i < 2 * (qEnd - qBase); i += 256) sPairs[i] = a.pairs[2 * size_t(qBase) + i];
+    }
+    __syncthreads();
+
+    for (uint32_t it0 = 0; it0 < nItems; it0 += NS) {    // uniform over the work group
+        uint32_t const it = it0 + slot;
+        bool const live = (it < nItems);
+        uint32_t const k = (live ? it : 0) / NSUB, y = first + k;
+        size_t const off = size_t(y) * 2 * P + ex;
+        EpiElem<R, EPI, false> eo;
+        if (live) eo.load(a, off, P);
+        R yr = 0, yi = 0;
+        if (inLds) {
+            uint32_t const q0 = live ? sStarts[k] - qBase : 0, q1 = live ? sStarts[k + 1] - qBase : 0;
+            for (uint32_t qb = q0; __any(qb < q1); qb += NB) {
+                R ar[NB], ai[NB], xr[NB], xi[NB];
+                uint32_t ia[NB], ix[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {           // (unconditional, inside the patch: all NB reads in flight at once)
+                    uint32_t const qc = min(qb + u, kPairs - 1);
+                    ia[u] = sPairs[2 * qc]; ix[u] = sPairs[2 * qc + 1];
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    ar[u] = 0; ai[u] = 0; xr[u] = 0; xi[u] = 0;
+                    if (qb + u < q1) {
+                        R const* Ab = (R const*)a.A + size_t(ia[u]) * 2 * (LM * LM);
+                        R const* Xb = (R const*)a.X + size_t(ix[u]) * 2 * P;
+                        ar[u] = Ab[ea]; ai[u] = Ab[LM * LM + ea]; xr[u] = Xb[ex]; xi[u] = Xb[P + ex];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    if (u > 0 && !__any(qb + u < q1)) continue;
+                    yr = __builtin_amdgcn_mfma_f64_4x4x4f64(ar[u], xr[u], yr, 0, 0, 0);
+                    yr = __builtin_amdgcn_mfma_f64_4x4x4f64(-ai[u], xi[u], yr, 0, 0, 0);
+                    yi = __builtin_amdgcn_mfma_f64_4x4x4f64(ar[u], xi[u], yi, 0, 0, 0);
+                    yi = __builtin_amdgcn_mfma_f64_4x4x4f64(ai[u], xr[u], yi, 0, 0, 0);
+                }
+            }
+        } else {   // a chunk whose index data exceed the LDS patch (rows of hundreds of products): one product at a time, from global memory
+            uint32_t const q0 = live ? a.starts[y] : 0, q1 = live ? a.starts[y + 1] : 0;
+            for (uint32_t q = q0; __any(q < q1); ++q) {
+                R ar = 0, ai = 0, xr = 0, xi = 0;
+                if (q < q1) {
+                    R const* Ab = (R const*)a.A + size_t(a.pairs[2 * size_t(q)]) * 2 * (LM * LM);
+                    R const* Xb = (R const*)a.X + size_t(a.pairs[2 * size_t(q) + 1]) * 2 * P;
+                    ar = Ab[ea]; ai = Ab[LM * LM + ea]; xr = Xb[ex]; xi = Xb[P + ex];
+                }
+                yr = __builtin_amdgcn_mfma_f64_4x4x4f64(ar, xr, yr, 0, 0, 0);
+                yr = __builtin_amdgcn_mfma_f64_4x4x4f64(-ai, xi, yr, 0, 0, 0);
+                yi = __builtin_amdgcn_mfma_f64_4x4x4f64(ar, xi, yi, 0, 0, 0);
+                yi = __builtin_amdgcn_mfma_f64_4x4x4f64(ai, xr, yi, 0, 0, 0);
+            }
+        }
+        if (live) {
+            uint32_t bq = 0xffffffffu;
+            if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX ? a.bOfX[y] : y;
+            epilogue_apply<R, EPI, false>(a, off, P, yr, yi, sr, si, eo, bq, ex, part);
+        }
+    }
+
+    if constexpr (NPL > 0) {
+        // lanes that share a block column: the slots with the same column quad, 4 rows each; added in a fixed order
+        __shared__ double red[NPL][256];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) red[p][t] = part[p];
+        __syncthreads();
+        for (int x = t; x < NPL * LN; x += 256) {
+            int const p = x / LN, jx = x % LN;
+            double sum = 0;
+#pragma unroll 1
+            for (int ss = jx / 4; ss < NS; ss += NSUB)
+                for (int r = 0; r < LM; ++r) sum += red[p][(ss / 4) * 64 + r * 16 + (ss % 4) * 4 + jx % 4];
+            write_record<EPI>(a, chunk, LN, p, jx, sum);
+        }
+        if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
+    }
+}
+
+// which 4-row shapes take k_spmm_m4
+template <typename R, int LM, int LN> constexpr bool kMfma4 = (LM == 4 && sizeof(R) == 8 && (LN == 4 || LN == 8));
 
 // which shapes take k_spmm_mfma8: all 8-row ones; of the 4-row ones only 4 x 32 in double -- elsewhere the half-empty tile
 // moves too few bytes per memory instruction and k_spmm_small4 wins (measured, 5-point stencils of 256 MB per vector,
@@ -2190,6 +2322,11 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
         if (pre8 && use_pre8) k_spmm_mfma8<R, LM, LN, EPI, pre8><<<dim3(nWG), dim3(256), 0, s>>>(a);
         else k_spmm_mfma8<R, LM, LN, EPI, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
     }
+    else if constexpr (kMfma4<R, LM, LN>) {
+        static int const use_m4 = lab_switch("TFQMRGPU_M4", 1);
+        if (use_m4) k_spmm_m4<LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
+        else k_spmm_small4<R, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
+    }
     else if constexpr (LM == 4) k_spmm_small4<R, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
     else k_spmm_direct<R, LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
 }
@@ -2250,6 +2387,7 @@ char const* spmm_kernel_family(DevPlan const& d) {
     if (8 == LM && (32 == LN || 64 == LN || 9 == LN || 10 == LN) && z && d.ilv) return "k_spmm_ilv8w";
     if (LM % 16 == 0 && LN % 16 == 0) return "k_spmm_mfma";
     if (8 == LM || (4 == LM && z && 32 == LN)) return "k_spmm_mfma8";
+    if (4 == LM && z && (4 == LN || 8 == LN) && lab_switch("TFQMRGPU_M4", 1)) return "k_spmm_m4";
     if (4 == LM) return "k_spmm_small4";
     return "k_spmm_direct";
 }
