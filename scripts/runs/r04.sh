@@ -366,5 +366,17 @@ an)
   done
   cat gpurun_out/r04an_ab.txt
   ;;
+ap)
+  # k_spmm_m4 with two neighbouring columns per lane (16-byte X and epilogue accesses) where LN % 8 == 0: 4 x 8 and 4 x 32 z, lab switch TFQMRGPU_M4 = 0 | 1 (0 = small4 | the tile kernel)
+  step 900 r04ap_tests.log python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py tests/test_gpu_operator.py tests/test_gpu_mixed.py -q
+  tail -n 3 gpurun_out/r04ap_tests.log
+  export AB_ALL=1
+  for wl in st:4:8:z:362:362:4 st:4:32:z:181:181:4 st:4:4:z:512:512:4; do
+    echo "## $wl" >> gpurun_out/r04ap_ab.txt
+    step 400 r04ap_one.txt python scripts/ab_fused.py $wl lab@TFQMRGPU_M4=0 lab@TFQMRGPU_M4=1 lab@TFQMRGPU_M4=0 lab@TFQMRGPU_M4=1
+    grep -v amdgpu.ids gpurun_out/r04ap_one.txt | grep -v "^    " >> gpurun_out/r04ap_ab.txt
+  done
+  cat gpurun_out/r04ap_ab.txt
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac

@@ -23,7 +23,7 @@
 //    instances recompute the shadow vector from its hash instead of reading it (HASH).
 //  * k_spmm_mfma8 : LM == 8 (and 4 x 32 z): [Re A; Im A] x [Re X | Im X] fills one 16 x 16 tile per 8 block columns (LN = 9,
 //    10: the last tile is masked; LM == 4: half of the rows are empty -- the matrix pipe is idle in these HBM-bound shapes).
-//  * k_spmm_m4     : 4 x 4 and 4 x 8 in double: four 4 x 4 x 4 products per v_mfma_f64_4x4x4_4b_f64, one element per lane, no LDS.
+//  * k_spmm_m4     : 4 x 4 | 8 | 32 in double: four 4 x 4 x 4 products per v_mfma_f64_4x4x4_4b_f64, elements straight from the planes, no LDS.
 //  * k_spmm_small4 : the other 4-row shapes: one lane per element, operands once per thread group through LDS.
 //  * k_spmm_direct : one thread per output element; only as the epilogue of a user-defined operator,
 //    operands through the vector L1.
@@ -2032,13 +2032,17 @@ __global__ __launch_bounds__(256) void k_spmm_small4(SpmmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 4 x 4 and 4 x 8 blocks in double: four 4 x 4 x 4 products per v_mfma_f64_4x4x4_4b_f64.  The instruction keeps its four
-// blocks interleaved at 4 lanes (measured with one-hot operands, scripts/mfma4_probe.hip): with lo = lane % 4,
+// 4-row blocks in double whose columns come in fours: four 4 x 4 x 4 products per v_mfma_f64_4x4x4_4b_f64.  The instruction
+// keeps its four blocks interleaved at 4 lanes (measured with one-hot operands, scripts/mfma4_probe.hip): with lo = lane % 4,
 // b = lane / 4 % 4, hi = lane / 16 a lane holds  A_b[i = lo][k = hi],  B_b[k = hi][j = lo]  and receives  D_b[i = hi][j = lo].
-// A blocks are stored as [k][i] and X, Y blocks as [i][j], so every lane loads and stores ONE element per plane at
-// hi * 4 + lo (A) or hi * LN + column quad + lo (X, Y): no LDS patch, no broadcast -- k_spmm_small4 spends 25 LDS
-// instructions per Y block on them.  A slot (b of a wave, 16 per work group) walks over Y sub-blocks of 4 x 4; the four
-// slots of a wave step together, a slot that has run out of products feeds zeros.
+// A blocks are stored as [k][i] and X, Y blocks as [i][j], so a lane loads and stores its elements straight from the planes,
+// at hi * 4 + lo (A) and hi * LN + its column(s) (X, Y): no LDS patch, no broadcast -- k_spmm_small4 spends 25 LDS
+// instructions per Y block on them.  Where LN is a multiple of 8 a lane keeps W = 2 NEIGHBOURING columns (the 4 x 4
+// products of the even and of the odd columns of an octet: which four columns share a product is free), so that X and
+// every epilogue vector move as 16-byte accesses -- the memory pipe retires one wave-wide access per 16 clocks whatever
+// its width (scripts/ta_rate.hip), and these kernels are bound by that rate (profiles/r04_small_shapes.txt).
+// A slot (b of a wave, 16 per work group) walks over Y sub-blocks of 4 x 4 W columns; the four slots of a wave step
+// together, a slot that has run out of products feeds zeros.
 #ifndef TFQ_M4_NB
 #define TFQ_M4_NB 8
 #endif
@@ -2046,27 +2050,33 @@ template <int LN, int EPI>
 __global__ __launch_bounds__(256) void k_spmm_m4(SpmmArgs a) {
     using R = double;
     if (gate_closed(a)) return;
-    constexpr int LM = 4, P = LM * LN, NSUB = LN / 4, NS = 16, NB = TFQ_M4_NB;
+    constexpr int W = (LN % 8 == 0) ? 2 : 1;             // neighbouring columns of a lane
+    constexpr int LM = 4, P = LM * LN, CQ = 4 * W, NSUB = LN / CQ, NS = 16, NB = TFQ_M4_NB / W;
     constexpr int NPL = EpiPlanes<EPI>::N;
-    static_assert(LN % 4 == 0 && NS % NSUB == 0, "a slot keeps its column quad");
+    static_assert(LN % CQ == 0 && NS % NSUB == 0, "a slot keeps its column group");
     int const t = threadIdx.x, wv = t >> 6, lane = t & 63;
     int const lo = lane & 3, b = (lane >> 2) & 3, hi = lane >> 4;
     int const slot = wv * 4 + b;
-    int const j = (slot % NSUB) * 4 + lo;                // block column of this lane (X and Y)
-    int const ea = hi * LM + lo, ex = hi * LN + j;       // this lane's element of an A block, of an X or Y block
+    int const j0 = (slot % NSUB) * CQ + W * lo;          // first block column of this lane (X and Y)
+    int const ea = hi * LM + lo, ex = hi * LN + j0;      // this lane's element of an A block, its first of an X or Y block
     uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;   // XCD-aware launch order (tfq_plan.cpp)
     uint32_t first, last, col = 0;
     if (a.chunkFirst) { first = a.chunkFirst[chunk]; last = a.chunkFirst[chunk + 1]; col = a.chunkCol[chunk]; }
     else { first = chunk * a.CH; last = min(first + a.CH, a.nY); }
 
-    R sr = 0, si = 0;
+    R sr[W], si[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { sr[w] = 0; si[w] = 0; }
     if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
-        sr = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + j];
-        si = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + j];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            sr[w] = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + j0 + w];
+            si[w] = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + j0 + w];
+        }
     }
-    double part[NPL > 0 ? NPL : 1] = {};
+    double part[NPL > 0 ? NPL : 1][W] = {};
 
-    // An item = a 4 x 4 sub-block of a Y block (item % NSUB == slot % NSUB); slot s takes items s, s + 16, ...  Three dependent
+    // An item = a 4 x CQ sub-block of a Y block (item % NSUB == slot % NSUB); slot s takes items s, s + 16, ...  Three dependent
     // requests lead to a product (row range -> index pairs -> operands).  The work group fetches the row ranges and the index
     // pairs of its whole chunk into LDS first (two latencies, once), so that a trip -- up to NB products of four items per
     // wave -- waits for ONE memory latency; k_spmm_small4 waits for two per product.
@@ -2082,18 +2092,30 @@ __global__ __launch_bounds__(256) void k_spmm_m4(SpmmArgs a) {
     }
     __syncthreads();
 
+    auto product = [&](R ar, R ai, R const (&xr)[W], R const (&xi)[W], R (&yr)[W], R (&yi)[W]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            yr[w] = __builtin_amdgcn_mfma_f64_4x4x4f64(ar, xr[w], yr[w], 0, 0, 0);
+            yr[w] = __builtin_amdgcn_mfma_f64_4x4x4f64(-ai, xi[w], yr[w], 0, 0, 0);
+            yi[w] = __builtin_amdgcn_mfma_f64_4x4x4f64(ar, xi[w], yi[w], 0, 0, 0);
+            yi[w] = __builtin_amdgcn_mfma_f64_4x4x4f64(ai, xr[w], yi[w], 0, 0, 0);
+        }
+    };
+
     for (uint32_t it0 = 0; it0 < nItems; it0 += NS) {    // uniform over the work group
         uint32_t const it = it0 + slot;
         bool const live = (it < nItems);
         uint32_t const k = (live ? it : 0) / NSUB, y = first + k;
         size_t const off = size_t(y) * 2 * P + ex;
-        EpiElem<R, EPI, false> eo;
+        EpiOps<R, EPI, W> eo;
         if (live) eo.load(a, off, P);
-        R yr = 0, yi = 0;
+        R yr[W], yi[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) { yr[w] = 0; yi[w] = 0; }
         if (inLds) {
             uint32_t const q0 = live ? sStarts[k] - qBase : 0, q1 = live ? sStarts[k + 1] - qBase : 0;
             for (uint32_t qb = q0; __any(qb < q1); qb += NB) {
-                R ar[NB], ai[NB], xr[NB], xi[NB];
+                R ar[NB], ai[NB], xr[NB][W], xi[NB][W];
                 uint32_t ia[NB], ix[NB];
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {           // (unconditional, inside the patch: all NB reads in flight at once)
@@ -2102,56 +2124,56 @@ __global__ __launch_bounds__(256) void k_spmm_m4(SpmmArgs a) {
                 }
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    ar[u] = 0; ai[u] = 0; xr[u] = 0; xi[u] = 0;
+                    ar[u] = 0; ai[u] = 0;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) { xr[u][w] = 0; xi[u][w] = 0; }
                     if (qb + u < q1) {
                         R const* Ab = (R const*)a.A + size_t(ia[u]) * 2 * (LM * LM);
                         R const* Xb = (R const*)a.X + size_t(ix[u]) * 2 * P;
-                        ar[u] = Ab[ea]; ai[u] = Ab[LM * LM + ea]; xr[u] = Xb[ex]; xi[u] = Xb[P + ex];
+                        ar[u] = Ab[ea]; ai[u] = Ab[LM * LM + ea]; vload<R, W>(xr[u], Xb + ex); vload<R, W>(xi[u], Xb + P + ex);
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
                     if (u > 0 && !__any(qb + u < q1)) continue;
-                    yr = __builtin_amdgcn_mfma_f64_4x4x4f64(ar[u], xr[u], yr, 0, 0, 0);
-                    yr = __builtin_amdgcn_mfma_f64_4x4x4f64(-ai[u], xi[u], yr, 0, 0, 0);
-                    yi = __builtin_amdgcn_mfma_f64_4x4x4f64(ar[u], xi[u], yi, 0, 0, 0);
-                    yi = __builtin_amdgcn_mfma_f64_4x4x4f64(ai[u], xr[u], yi, 0, 0, 0);
+                    product(ar[u], ai[u], xr[u], xi[u], yr, yi);
                 }
             }
         } else {   // a chunk whose index data exceed the LDS patch (rows of hundreds of products): one product at a time, from global memory
             uint32_t const q0 = live ? a.starts[y] : 0, q1 = live ? a.starts[y + 1] : 0;
             for (uint32_t q = q0; __any(q < q1); ++q) {
-                R ar = 0, ai = 0, xr = 0, xi = 0;
+                R ar = 0, ai = 0, xr[W], xi[W];
+#pragma unroll
+                for (int w = 0; w < W; ++w) { xr[w] = 0; xi[w] = 0; }
                 if (q < q1) {
                     R const* Ab = (R const*)a.A + size_t(a.pairs[2 * size_t(q)]) * 2 * (LM * LM);
                     R const* Xb = (R const*)a.X + size_t(a.pairs[2 * size_t(q) + 1]) * 2 * P;
-                    ar = Ab[ea]; ai = Ab[LM * LM + ea]; xr = Xb[ex]; xi = Xb[P + ex];
+                    ar = Ab[ea]; ai = Ab[LM * LM + ea]; vload<R, W>(xr, Xb + ex); vload<R, W>(xi, Xb + P + ex);
                 }
-                yr = __builtin_amdgcn_mfma_f64_4x4x4f64(ar, xr, yr, 0, 0, 0);
-                yr = __builtin_amdgcn_mfma_f64_4x4x4f64(-ai, xi, yr, 0, 0, 0);
-                yi = __builtin_amdgcn_mfma_f64_4x4x4f64(ar, xi, yi, 0, 0, 0);
-                yi = __builtin_amdgcn_mfma_f64_4x4x4f64(ai, xr, yi, 0, 0, 0);
+                product(ar, ai, xr, xi, yr, yi);
             }
         }
         if (live) {
             uint32_t bq = 0xffffffffu;
             if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX ? a.bOfX[y] : y;
-            epilogue_apply<R, EPI, false>(a, off, P, yr, yi, sr, si, eo, bq, ex, part);
+            epilogue_row<R, EPI, W, NPL, W>(a, off, P, yr, yi, sr, si, 0, eo, bq, ex, part, 0);
         }
     }
 
     if constexpr (NPL > 0) {
-        // lanes that share a block column: the slots with the same column quad, 4 rows each; added in a fixed order
-        __shared__ double red[NPL][256];
+        // lanes that share a block column: the slots with the same column group, 4 rows each; added in a fixed order
+        __shared__ double red[NPL][W][256];
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) red[p][t] = part[p];
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int w = 0; w < W; ++w) red[p][w][t] = part[p][w];
         __syncthreads();
         for (int x = t; x < NPL * LN; x += 256) {
-            int const p = x / LN, jx = x % LN;
+            int const p = x / LN, jx = x % LN, jl = (jx % CQ) / W, jw = jx % W;
             double sum = 0;
 #pragma unroll 1
-            for (int ss = jx / 4; ss < NS; ss += NSUB)
-                for (int r = 0; r < LM; ++r) sum += red[p][(ss / 4) * 64 + r * 16 + (ss % 4) * 4 + jx % 4];
+            for (int ss = jx / CQ; ss < NS; ss += NSUB)
+                for (int r = 0; r < LM; ++r) sum += red[p][jw][(ss / 4) * 64 + r * 16 + (ss % 4) * 4 + jl];
             write_record<EPI>(a, chunk, LN, p, jx, sum);
         }
         if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
@@ -2159,7 +2181,7 @@ __global__ __launch_bounds__(256) void k_spmm_m4(SpmmArgs a) {
 }
 
 // which 4-row shapes take k_spmm_m4
-template <typename R, int LM, int LN> constexpr bool kMfma4 = (LM == 4 && sizeof(R) == 8 && (LN == 4 || LN == 8));
+template <typename R, int LM, int LN> constexpr bool kMfma4 = (LM == 4 && sizeof(R) == 8 && LN % 4 == 0);
 
 // which shapes take k_spmm_mfma8: all 8-row ones; of the 4-row ones only 4 x 32 in double -- elsewhere the half-empty tile
 // moves too few bytes per memory instruction and k_spmm_small4 wins (measured, 5-point stencils of 256 MB per vector,
@@ -2172,6 +2194,10 @@ template <typename R, int LM, int LN> constexpr bool kTile8 = (LM == 8) || (LM =
 template <typename R, int LM, int LN, int EPI>
 static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
     if (0 == nWG) return;
+    if constexpr (kMfma4<R, LM, LN>) {   // (lab: TFQMRGPU_M4=0 = the kernels these shapes had before, k_spmm_small4 and the half-empty tile of k_spmm_mfma8)
+        static int const use_m4 = lab_switch("TFQMRGPU_M4", 1);
+        if (use_m4) { k_spmm_m4<LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a); return; }
+    }
     if constexpr (LM == 16 && LN == 16 && sizeof(R) == 8) {
         if (a.ilv && a.chunkFirst) {   // the plan keeps its blocks row-pair-interleaved (tfq_plan.cpp: layoutBuffer); never the plain mode
             constexpr bool canHashI = (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT);
@@ -2322,11 +2348,6 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
         if (pre8 && use_pre8) k_spmm_mfma8<R, LM, LN, EPI, pre8><<<dim3(nWG), dim3(256), 0, s>>>(a);
         else k_spmm_mfma8<R, LM, LN, EPI, false><<<dim3(nWG), dim3(256), 0, s>>>(a);
     }
-    else if constexpr (kMfma4<R, LM, LN>) {
-        static int const use_m4 = lab_switch("TFQMRGPU_M4", 1);
-        if (use_m4) k_spmm_m4<LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
-        else k_spmm_small4<R, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
-    }
     else if constexpr (LM == 4) k_spmm_small4<R, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
     else k_spmm_direct<R, LM, LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a);
 }
@@ -2386,8 +2407,8 @@ char const* spmm_kernel_family(DevPlan const& d) {
     if (8 == LM && (8 == LN || 32 == LN || 64 == LN) && !z && 4 == d.ilv) return "k_spmm_ilv8f";
     if (8 == LM && (32 == LN || 64 == LN || 9 == LN || 10 == LN) && z && d.ilv) return "k_spmm_ilv8w";
     if (LM % 16 == 0 && LN % 16 == 0) return "k_spmm_mfma";
+    if (4 == LM && z && LN % 4 == 0 && lab_switch("TFQMRGPU_M4", 1)) return "k_spmm_m4";
     if (8 == LM || (4 == LM && z && 32 == LN)) return "k_spmm_mfma8";
-    if (4 == LM && z && (4 == LN || 8 == LN) && lab_switch("TFQMRGPU_M4", 1)) return "k_spmm_m4";
     if (4 == LM) return "k_spmm_small4";
     return "k_spmm_direct";
 }
@@ -2452,7 +2473,8 @@ tfqmrgpuStatus_t launch_multiply(char precision, int lm, int ln, uint32_t nnzbY,
     int const mu = mt / ms;                               // strips per Y block
     uint32_t ch = (mu >= 4) ? 1 : 4 / mu;                 // one strip per wave
     if (!mfma) ch = (4 == lm) ? 64 : (lm * ln >= 256) ? 1 : 256 / (lm * ln); // k_spmm_small4: a few sub-blocks per thread group
-    if (8 == lm || (4 == lm && dbl && 32 == ln)) ch = (4 == lm) ? 16 : 4;   // k_spmm_mfma8 (kTile8): one Y block per wave and pass
+    if (8 == lm) ch = 4;                                  // k_spmm_mfma8 (kTile8): one Y block per wave and pass
+    if (4 == lm && dbl && 32 == ln) ch = 16;              // k_spmm_m4: 64 items, four per Y block (and the tile kernel's 16 before it)
     a.CH = ch;
     uint32_t nWG = (nnzbY + ch - 1) / ch;
     // (lab: contiguous eighths of the caller's Y blocks per XCD instead of round-robin work groups)
