@@ -378,5 +378,29 @@ ap)
   done
   cat gpurun_out/r04ap_ab.txt
   ;;
+aq)
+  # A blocks of the k_spmm_m4 plans as complex pairs [k][i][re, im] (one 16-byte A access per lane and product): lab switch TFQMRGPU_A_CPLX = 0 | 1 (slower, not shipped: the change is not in the tree)
+  step 900 r04aq_tests.log python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py tests/test_gpu_operator.py tests/test_gpu_mixed.py -q
+  tail -n 3 gpurun_out/r04aq_tests.log
+  export AB_ALL=1
+  for wl in st:4:4:z:512:512:4 st:4:8:z:362:362:4 st:4:32:z:181:181:4; do
+    echo "## $wl" >> gpurun_out/r04aq_ab.txt
+    step 400 r04aq_one.txt python scripts/ab_fused.py $wl lab@TFQMRGPU_A_CPLX=0 lab@TFQMRGPU_A_CPLX=1 lab@TFQMRGPU_A_CPLX=0 lab@TFQMRGPU_A_CPLX=1
+    grep -v amdgpu.ids gpurun_out/r04aq_one.txt | grep -v "^    " >> gpurun_out/r04aq_ab.txt
+  done
+  cat gpurun_out/r04aq_ab.txt
+  ;;
+ar)
+  # k_spmm_small4 with its chunk's index data in LDS and the operands of up to 6 | 8 products requested at once: previous commit | this one
+  step 900 r04ar_tests.log python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py tests/test_gpu_operator.py tests/test_gpu_mixed.py -q
+  tail -n 3 gpurun_out/r04ar_tests.log
+  export AB_ALL=1
+  for wl in st:4:5:z:457:457:4 st:4:4:c:724:724:4 st:4:5:c:647:647:4 st:4:8:c:512:512:4 st:4:32:c:256:256:4; do
+    echo "## $wl" >> gpurun_out/r04ar_ab.txt
+    step 400 r04ar_one.txt python scripts/ab_fused.py $wl scripts/bin/libtfQMRgpu_prev.so default scripts/bin/libtfQMRgpu_prev.so default
+    grep -v amdgpu.ids gpurun_out/r04ar_one.txt | grep -v "^    " >> gpurun_out/r04ar_ab.txt
+  done
+  cat gpurun_out/r04ar_ab.txt
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac

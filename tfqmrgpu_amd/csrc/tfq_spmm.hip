@@ -1974,40 +1974,89 @@ __global__ __launch_bounds__(256) void k_spmm_small4(SpmmArgs a) {
     }
     double part[NPL > 0 ? NPL : 1] = {};
 
-    uint32_t const nItems = (last - first) * NSUB;       // item = sub-block of a Y block; item % NSUB == g % NSUB
-    for (uint32_t it = g; it < nItems; it += NG) {
-        uint32_t const y = first + it / NSUB;
-        uint32_t const q0 = a.starts[y], q1 = a.starts[y + 1];
-        R pa[2] = {0, 0}, px[2] = {0, 0};                // operands of the next product, in flight
-        auto fetch = [&](uint32_t q) __attribute__((always_inline)) {
-            R const* Ab = (R const*)a.A + size_t(a.pairs[2 * size_t(q)]) * 2 * (LM * LM);
-            R const* Xb = (R const*)a.X + size_t(a.pairs[2 * size_t(q) + 1]) * 2 * P;
-            if (e < LM * LM) { pa[0] = Ab[e]; pa[1] = Ab[LM * LM + e]; }
-            if (valid) { px[0] = Xb[i * LN + j]; px[1] = Xb[P + i * LN + j]; }
-        };
-        R yr = 0, yi = 0;
-        if (q0 < q1) fetch(q0);
-        for (uint32_t q = q0; q < q1; ++q) {
-            __builtin_amdgcn_wave_barrier();
-            if (e < LM * LM) { As[g][0][e] = pa[0]; As[g][1][e] = pa[1]; }
-            if (valid) { Xs[g][0][e] = px[0]; Xs[g][1][e] = px[1]; }
-            if (q + 1 < q1) fetch(q + 1);
-            __builtin_amdgcn_wave_barrier();
-            R cr = 0, ci = 0;
+    // Three dependent requests lead to a product (row range -> index pairs -> operands).  As in k_spmm_m4 the work group fetches
+    // the row ranges and index pairs of its whole chunk into LDS first, and a thread group requests the operands of up to NB
+    // products before it multiplies the first: one memory latency per NB products instead of two per product.
+    constexpr uint32_t kRows = 256, kPairs = 2048;       // (a float chunk of 4 x 4 blocks has 128 rows)
+    constexpr int NB = (sizeof(R) == 8) ? 6 : 8;
+    __shared__ uint32_t sStarts[kRows + 1];
+    __shared__ uint32_t sPairs[2 * kPairs];
+    uint32_t const nRows = last - first, nItems = nRows * NSUB;   // item = sub-block of a Y block; item % NSUB == g % NSUB
+    uint32_t const qBase = a.starts[first], qEnd = a.starts[last];
+    bool const inLds = (nRows <= kRows) && (qEnd - qBase <= kPairs);
+    if (inLds) {
+        for (uint32_t i = t; i <= nRows; i += 256) sStarts[i] = a.starts[first + i];
+        for (uint32_t i = t; i < 2 * (qEnd - qBase); i += 256) sPairs[i] = a.pairs[2 * size_t(qBase) + i];
+    }
+    __syncthreads();
+
+    auto multiply = [&](R const (&pa)[2], R const (&px)[2], R& yr, R& yi) __attribute__((always_inline)) {
+        __builtin_amdgcn_wave_barrier();
+        if (e < LM * LM) { As[g][0][e] = pa[0]; As[g][1][e] = pa[1]; }
+        if (valid) { Xs[g][0][e] = px[0]; Xs[g][1][e] = px[1]; }
+        __builtin_amdgcn_wave_barrier();
+        R cr = 0, ci = 0;
 #pragma unroll
-            for (int k = 0; k < LM; ++k) {
-                R const ar = As[g][0][k * LM + i], ai = As[g][1][k * LM + i];
-                R const xr = Xs[g][0][k * LNS + jj], xi = Xs[g][1][k * LNS + jj];
-                cr = fma_(-ai, xi, fma_(ar, xr, cr));
-                ci = fma_(ai, xr, fma_(ar, xi, ci));
+        for (int k = 0; k < LM; ++k) {
+            R const ar = As[g][0][k * LM + i], ai = As[g][1][k * LM + i];
+            R const xr = Xs[g][0][k * LNS + jj], xi = Xs[g][1][k * LNS + jj];
+            cr = fma_(-ai, xi, fma_(ar, xr, cr));
+            ci = fma_(ai, xr, fma_(ar, xi, ci));
+        }
+        yr += cr; yi += ci;
+    };
+
+    for (uint32_t it = g; it < nItems; it += NG) {
+        uint32_t const kr = it / NSUB, y = first + kr;
+        int const eb = i * LN + j;
+        size_t const off = size_t(y) * 2 * P + eb;
+        EpiElem<R, EPI, false> eo;
+        if (valid) eo.load(a, off, P);
+        R yr = 0, yi = 0;
+        if (inLds) {
+            uint32_t const q0 = sStarts[kr] - qBase, q1 = sStarts[kr + 1] - qBase;
+            for (uint32_t qb = q0; qb < q1; qb += NB) {
+                R pa[NB][2], px[NB][2];
+                uint32_t ia[NB], ix[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {           // (unconditional, inside the patch: all NB reads in flight at once)
+                    uint32_t const qc = min(qb + u, kPairs - 1);
+                    ia[u] = sPairs[2 * qc]; ix[u] = sPairs[2 * qc + 1];
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    pa[u][0] = 0; pa[u][1] = 0; px[u][0] = 0; px[u][1] = 0;
+                    if (qb + u < q1) {
+                        R const* Ab = (R const*)a.A + size_t(ia[u]) * 2 * (LM * LM);
+                        R const* Xb = (R const*)a.X + size_t(ix[u]) * 2 * P;
+                        if (e < LM * LM) { pa[u][0] = Ab[e]; pa[u][1] = Ab[LM * LM + e]; }
+                        if (valid) { px[u][0] = Xb[i * LN + j]; px[u][1] = Xb[P + i * LN + j]; }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u)
+                    if (qb + u < q1) multiply(pa[u], px[u], yr, yi);
             }
-            yr += cr; yi += ci;
+        } else {   // a chunk whose index data exceed the LDS patch: one product in flight, indices from global memory
+            uint32_t const q0 = a.starts[y], q1 = a.starts[y + 1];
+            R pa[2] = {0, 0}, px[2] = {0, 0};                // operands of the next product, in flight
+            auto fetch = [&](uint32_t q) __attribute__((always_inline)) {
+                R const* Ab = (R const*)a.A + size_t(a.pairs[2 * size_t(q)]) * 2 * (LM * LM);
+                R const* Xb = (R const*)a.X + size_t(a.pairs[2 * size_t(q) + 1]) * 2 * P;
+                if (e < LM * LM) { pa[0] = Ab[e]; pa[1] = Ab[LM * LM + e]; }
+                if (valid) { px[0] = Xb[i * LN + j]; px[1] = Xb[P + i * LN + j]; }
+            };
+            if (q0 < q1) fetch(q0);
+            for (uint32_t q = q0; q < q1; ++q) {
+                R const ca[2] = {pa[0], pa[1]}, cx[2] = {px[0], px[1]};
+                if (q + 1 < q1) fetch(q + 1);
+                multiply(ca, cx, yr, yi);
+            }
         }
         if (valid) {
             uint32_t bq = 0xffffffffu;
             if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX ? a.bOfX[y] : y;
-            int const eb = i * LN + j;
-            epilogue<R, EPI, false>(a, size_t(y) * 2 * P + eb, P, yr, yi, sr, si, bq, eb, part);
+            epilogue_apply<R, EPI, false>(a, off, P, yr, yi, sr, si, eo, bq, eb, part);
         }
     }
 
