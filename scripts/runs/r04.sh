@@ -402,5 +402,15 @@ ar)
   done
   cat gpurun_out/r04ar_ab.txt
   ;;
+as)
+  # k_spmm_ilv8w with the operands of 4 | 6 (8 x 9, 8 x 10) and 3 | 4 (8 x 32, 8 x 64) products requested at once instead of two refilled sets: variant builds w4 | w6 against the tree (slower: the change is not in the tree)
+  export AB_ALL=1
+  for wl in st:8:9:z:241:241:4 st:8:10:z:228:228:4 st:8:32:z:128:128:4 st:8:64:z:90:90:4; do
+    echo "## $wl" >> gpurun_out/r04as_ab.txt
+    step 400 r04as_one.txt python scripts/ab_fused.py $wl default scripts/bin/libtfQMRgpu_w4.so scripts/bin/libtfQMRgpu_w6.so default
+    grep -v amdgpu.ids gpurun_out/r04as_one.txt | grep -v "^    " >> gpurun_out/r04as_ab.txt
+  done
+  cat gpurun_out/r04as_ab.txt
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac
