@@ -412,5 +412,17 @@ as)
   done
   cat gpurun_out/r04as_ab.txt
   ;;
+at)
+  # k_spmm_mfma8 (8 x 9 | 10 c) with its row ranges and index pairs as scalar loads: previous commit | tree
+  step 900 r04at_tests.log python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py tests/test_gpu_operator.py tests/test_gpu_mixed.py -q
+  tail -n 3 gpurun_out/r04at_tests.log
+  export AB_ALL=1
+  for wl in st:8:9:c:341:341:4 st:8:10:c:323:323:4; do
+    echo "## $wl" >> gpurun_out/r04at_ab.txt
+    step 400 r04at_one.txt python scripts/ab_fused.py $wl scripts/bin/libtfQMRgpu_prev.so default scripts/bin/libtfQMRgpu_prev.so default
+    grep -v amdgpu.ids gpurun_out/r04at_one.txt | grep -v "^    " >> gpurun_out/r04at_ab.txt
+  done
+  cat gpurun_out/r04at_ab.txt
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac

@@ -1844,6 +1844,11 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
     }
     double part[NPL > 0 ? NPL : 1][NT] = {};
 
+    // (row ranges and index pairs are the same for every lane of a wave: scalar loads from the constant address space -- as plain global
+    //  loads the index pair of a product was waited for with s_waitcnt vmcnt(0) right in front of its operand requests, which drained the
+    //  DEPTH products "in flight" every time; r04, profiles/r04_four_row_shapes.txt)
+    using CU32 = __attribute__((address_space(4))) uint32_t const*;
+    CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts;
     struct Ops { R a[KS]; R x[KS][NT]; };
     R const* const A0 = (R const*)a.A + (pa & 1) * (LM * LM) + ia;   // + k*LM
     R const* const X0 = (R const*)a.X + part8 * P + j8;              // + k*LN + nt*8
@@ -1851,7 +1856,7 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
         T4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = T4{0, 0, 0, 0};
-        uint32_t const q0 = a.starts[y], q1 = a.starts[y + 1];
+        uint32_t const q0 = starts[y], q1 = starts[y + 1];
         // the operands of this block's epilogue travel while its products are computed (PRE; TFQMRGPU_EPI_PREFETCH=0: behind them)
         EpiElem<R, EPI, LN == 8> eo[PRE ? NT : 1];
         if constexpr (PRE) {
@@ -1861,8 +1866,8 @@ __global__ __launch_bounds__(256) void k_spmm_mfma8(SpmmArgs a) {
                     eo[nt].load(a, size_t(y) * 2 * P + ei * LN + nt * 8 + ej, P);
         }
         auto fetch = [&](Ops& o, uint32_t q) {
-            R const* Ab = A0 + size_t(a.pairs[2 * size_t(q)]) * 2 * LM * LM;
-            R const* Xb = X0 + size_t(a.pairs[2 * size_t(q) + 1]) * 2 * P;
+            R const* Ab = A0 + size_t(pairs[2 * size_t(q)]) * 2 * LM * LM;
+            R const* Xb = X0 + size_t(pairs[2 * size_t(q) + 1]) * 2 * P;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 int const k = 4 * s + lr;
