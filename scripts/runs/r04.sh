@@ -424,5 +424,17 @@ at)
   done
   cat gpurun_out/r04at_ab.txt
   ;;
+au)
+  # the shadow key's index reads (block row of the Y block, original column) as scalar loads in the hash-mode kernels: previous commit | tree, P2, config 5, 16 x 16 c  (1-3 % slower on the norm multiply: not in the tree)
+  export AB_ALL=1
+  for wl in fd2d_16x16_z stencil2d_8x8_z st:16:16:c:181:181:4; do
+    echo "## $wl" >> gpurun_out/r04au_ab.txt
+    step 500 r04au_one.txt python scripts/ab_fused.py $wl scripts/bin/libtfQMRgpu_prev.so default scripts/bin/libtfQMRgpu_prev.so default
+    grep -v amdgpu.ids gpurun_out/r04au_one.txt | grep -v "^    " >> gpurun_out/r04au_ab.txt
+  done
+  cat gpurun_out/r04au_ab.txt
+  step 900 r04au_tests.log python -m pytest tests/test_gpu_hash_mode.py tests/test_gpu_parity.py -q
+  tail -n 3 gpurun_out/r04au_tests.log
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac
