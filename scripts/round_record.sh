@@ -3,7 +3,7 @@
 # command (-> profiles/rNN_rocprofv3_kernel_stats.csv), the other BASELINE configurations (-> profiles/rNN_configs.txt),
 # the whole GPU test suite and the smoke test.  usage: gpurun --timeout 1200 -- scripts/round_record.sh
 source scripts/gpu_steps.sh
-step 600 bench.json python bench.py --steps 5 --warmup 2
+step 600 bench.json python bench.py --steps 20 --warmup 5
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/stats
 step 400 rocprof_bench.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline
