@@ -448,16 +448,22 @@ def main():
                   s.get_matrix_device(dXout.data_ptr())
               torch.cuda.synchronize()
               resolve_ms = (time.perf_counter() - tr0) / args.steps * 1e3
+              # the same with pageable host arrays in the caller's own layout and precision, the C calls alone (numpy's allocation of the result and its
+              # conversion to a complex array are not the library's: they had made this figure 232 ms in r03/r04 where the three calls take 55)
+              hB = np.ascontiguousarray(pr.B.astype(np.complex128 if prec == "z" else np.complex64))
+              Xh = np.zeros((pr.nnzbX, pr.LM, pr.LN, 2), dtype=np.float64 if prec == "z" else np.float32)
+              Xh[:] = 1                                        # (pages touched: a caller's result array is not fresh from the kernel)
+              pc = prec.encode()
               th0 = time.perf_counter()
-              s.set_matrix("B", pr.B)
+              T._check(T.lib.tfqmrgpu_bsrsv_setMatrix(s.handle, s.plan, b"B", T._ptr(hB), pc, pr.LN, pr.LM, b"n", T.LAYOUT_RIRIRIRI), "setMatrix('B')")
               s.solve(pr.tolerance, args.max_iterations)
-              Xh = s.get_matrix()
+              T._check(T.lib.tfqmrgpu_bsrsv_getMatrix(s.handle, s.plan, b"X", T._ptr(Xh), pc, pr.LN, pr.LM, b"n", T.LAYOUT_RIRIRIRI), "getMatrix('X')")
               resolve_host_ms = (time.perf_counter() - th0) * 1e3
               resolve = dict(resolve_ms=round(resolve_ms, 3), over_solve=round(resolve_ms / (elapsed / args.steps * 1e3), 3),
                              resolve_host_arrays_ms=round(resolve_host_ms, 1),
                              note="setMatrix('B') + solve + getMatrix('X'); resolve_ms: B and X in device memory (converted in place by the library), "
-                                  "resolve_host_arrays_ms: pageable host arrays (X = %.0f MB over PCIe)" % (S_bytes(pr, prec) / 1e6))
-              del dB, dXout, Xh
+                                  "resolve_host_arrays_ms: pageable host arrays (X = %.0f MB over PCIe), the three C calls" % (S_bytes(pr, prec) / 1e6))
+              del dB, dXout, Xh, hB
 
             # the same system in mixed precision (bufferSize 'm': complex<float> tfQMR inside a refinement in double):
             # time to the SAME threshold in double arithmetic, beside the headline figure (which stays the complex<double> solve)

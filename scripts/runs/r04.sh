@@ -436,5 +436,16 @@ au)
   step 900 r04au_tests.log python -m pytest tests/test_gpu_hash_mode.py tests/test_gpu_parity.py -q
   tail -n 3 gpurun_out/r04au_tests.log
   ;;
+aw)
+  # pageable host arrays through two pinned bounce buffers (tfq_api.hip: piped_copy) against one hipMemcpy: lab switch TFQMRGPU_PIPED_COPY = 0 | 1
+  step 600 r04aw_tests.log python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py -q
+  tail -n 3 gpurun_out/r04aw_tests.log
+  for wl in fd2d_16x16_z stencil2d_8x8_z; do
+    for v in 0 1 0 1; do
+      TFQMRGPU_LIB=$GRAFT_REPO_ROOT/tfqmrgpu_amd/lib/libtfQMRgpu_lab.so TFQMRGPU_PIPED_COPY=$v python scripts/host_arrays.py $wl 5 2>&1 | grep -v amdgpu.ids >> gpurun_out/r04aw_host_arrays.txt
+    done
+  done
+  cat gpurun_out/r04aw_host_arrays.txt
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac

@@ -154,3 +154,16 @@ def test_the_library_names_the_kernel_family_of_a_plan(shape, prec, family):
         s.create_plan(pr)
         s.set_buffer(nbytes=s.buffer_size(lm, ln, prec))
         assert s.multiply_kernel() == family
+
+
+def test_large_host_arrays_round_trip_unchanged():
+    """setMatrix('X') / getMatrix('X') with pageable host arrays of 75 MB: every value returns to its place, twice over"""
+    pr = PR.stencil_2d(96, 96, 16, 16, 2, seed=11)          # 18 432 X blocks of 4 KiB
+    rng = np.random.default_rng(5)
+    with T.Solver() as s:
+        s.create_plan(pr)
+        s.set_buffer(nbytes=s.buffer_size(16, 16, "z"))
+        for _ in range(2):
+            X = (rng.standard_normal((pr.nnzbX, 16, 16)) + 1j * rng.standard_normal((pr.nnzbX, 16, 16)))
+            s.set_matrix("X", X)
+            assert np.array_equal(s.get_matrix(), X)
