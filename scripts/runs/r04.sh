@@ -437,7 +437,7 @@ au)
   tail -n 3 gpurun_out/r04au_tests.log
   ;;
 aw)
-  # pageable host arrays through two pinned bounce buffers (tfq_api.hip: piped_copy) against one hipMemcpy: lab switch TFQMRGPU_PIPED_COPY = 0 | 1
+  # pageable host arrays through two pinned bounce buffers (tfq_api.hip: piped_copy) against one hipMemcpy: lab switch TFQMRGPU_PIPED_COPY = 0 | 1 (slower; the pipeline is not in the tree)
   step 600 r04aw_tests.log python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py -q
   tail -n 3 gpurun_out/r04aw_tests.log
   for wl in fd2d_16x16_z stencil2d_8x8_z; do
