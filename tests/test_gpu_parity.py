@@ -566,8 +566,36 @@ def test_random_ragged_systems(oracle):
             assert np.abs(X - Xd).max() <= 1e-8 * np.abs(Xd).max(), (case, LM, LN)
 
 
+@pytest.mark.parametrize("prec,size", [("z", (4, 4)), ("z", (4, 8)), ("z", (4, 32)), ("z", (4, 5)), ("c", (4, 4)), ("c", (4, 5)), ("c", (4, 32)), ("c", (8, 9))])
+def test_multiply_rows_with_more_products_than_the_index_patch_holds(torch_cuda, oracle, prec, size):
+    """k_spmm_m4 and k_spmm_small4 keep the row ranges and index pairs of a chunk in LDS (1024 | 2048 pairs): 70 rows of 38-44 products each are
+    more than that, the work groups take their other path (one product at a time, indices from global memory) -- same sums, same order"""
+    torch = torch_cuda
+    LM, LN = size
+    rng = np.random.default_rng(LM * 1000 + LN)
+    nY, nA, nX = 70, 31, 45
+    starts, pairs = [0], []
+    for _ in range(nY):
+        for _ in range(int(rng.integers(38, 45))):
+            pairs += [int(rng.integers(0, nA)), int(rng.integers(0, nX))]
+        starts.append(len(pairs) // 2)
+    starts, pairs = np.array(starts, np.uint32), np.array(pairs, np.uint32)
+    real = np.float64 if prec == "z" else np.float32
+    A = rng.uniform(-1, 1, (nA, 2, LM, LM)).astype(real)
+    X = rng.uniform(-1, 1, (nX, 2, LM, LN)).astype(real)
+    want = oracle.spmm(prec, LM, LN, starts, pairs, A, np.concatenate([X, np.zeros((nY - nX, 2, LM, LN), real)]))[:nY]
+    dA, dX = torch.from_numpy(A).cuda(), torch.from_numpy(X).cuda()
+    dS, dP = torch.from_numpy(starts.view(np.int32)).cuda(), torch.from_numpy(pairs.view(np.int32)).cuda()
+    dY = torch.full((nY, 2, LM, LN), 7.0, dtype=dA.dtype, device="cuda")
+    with T.Solver() as s:
+        assert T.lib.tfqmrgpuExt_multiply(s.handle, prec.encode(), LM, LN, nY, dS.data_ptr(), dP.data_ptr(), dA.data_ptr(), dX.data_ptr(), dY.data_ptr()) == 0
+        torch.cuda.synchronize()
+    eps = 1e-13 if prec == "z" else 2e-5
+    assert np.abs(dY.cpu().numpy() - want).max() <= eps * LM * 44, (size, prec)
+
+
 @pytest.mark.parametrize("prec", ["z", "c"])
-@pytest.mark.parametrize("shape", [(16, 16), (8, 8), (4, 5), (32, 32), (16, 64), (32, 64), (64, 64)])
+@pytest.mark.parametrize("shape", [(16, 16), (8, 8), (4, 5), (4, 4), (4, 8), (4, 32), (8, 9), (32, 32), (16, 64), (32, 64), (64, 64)])
 def test_apply_operator_on_plan_data(oracle, prec, shape):
     """X := A*X with the solver's own multiply kernel and block / element order (16 x 16 z: row pairs interleaved)
     against the oracle's product on the caller's order (reference contract: tfqmrgpu_blockmult.hxx:9-93)"""
