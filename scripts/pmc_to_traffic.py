@@ -10,7 +10,7 @@ wl, summary, tag = sys.argv[1], json.load(open(sys.argv[2])), sys.argv[3]
 sha = sys.argv[4] if len(sys.argv) > 4 else subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 # where the epilogue number sits among the template arguments of each multiply family (tfq_spmm.hip), and where FIRST (first-iteration instance)
 EPI_AT = {"k_spmm_ilv16": 0, "k_spmm_ilv16f": 0, "k_spmm_ilv8": 0, "k_spmm_ilv8b": 0, "k_spmm_ilvf": 2, "k_spmm_ilv8w": 1, "k_spmm_ilv8f": 1,
-          "k_spmm_mfma": 3, "k_spmm_mfma8": 3, "k_spmm_small4": 2, "k_spmm_m4": 2, "k_spmm_direct": 3}
+          "k_spmm_mfma": 3, "k_spmm_mfma8": 3, "k_spmm_small4": 2, "k_spmm_m4": 2, "k_spmm_s4w": 2, "k_spmm_direct": 3}
 FIRST_LAST = {"k_spmm_ilv16", "k_spmm_ilv16f", "k_spmm_ilv8", "k_spmm_ilv8b", "k_spmm_ilvf", "k_spmm_ilv8w", "k_spmm_ilv8f"}
 VEC = {"k_xpay_v6": "xpay_v6", "k_v5_nrm": "v5_nrm", "k_x_v6_v7": "x_v6_v7"}
 entry, names = {}, {}

@@ -447,5 +447,17 @@ aw)
   done
   cat gpurun_out/r04aw_host_arrays.txt
   ;;
+ay)
+  # k_spmm_s4w (float 4 x 4 | 8 | 32: four neighbouring columns per lane, 16-byte accesses) against k_spmm_small4: lab switch TFQMRGPU_S4W = 0 | 1
+  step 900 r04ay_tests.log python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py tests/test_gpu_operator.py tests/test_gpu_mixed.py -q
+  tail -n 3 gpurun_out/r04ay_tests.log
+  export AB_ALL=1
+  for wl in st:4:4:c:724:724:4 st:4:8:c:512:512:4 st:4:32:c:256:256:4; do
+    echo "## $wl" >> gpurun_out/r04ay_ab.txt
+    step 400 r04ay_one.txt python scripts/ab_fused.py $wl lab@TFQMRGPU_S4W=0 lab@TFQMRGPU_S4W=1 lab@TFQMRGPU_S4W=0 lab@TFQMRGPU_S4W=1
+    grep -v amdgpu.ids gpurun_out/r04ay_one.txt | grep -v "^    " >> gpurun_out/r04ay_ab.txt
+  done
+  cat gpurun_out/r04ay_ab.txt
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac

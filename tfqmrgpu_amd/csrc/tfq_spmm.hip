@@ -24,6 +24,7 @@
 //  * k_spmm_mfma8 : LM == 8 (and 4 x 32 z): [Re A; Im A] x [Re X | Im X] fills one 16 x 16 tile per 8 block columns (LN = 9,
 //    10: the last tile is masked; LM == 4: half of the rows are empty -- the matrix pipe is idle in these HBM-bound shapes).
 //  * k_spmm_m4     : 4 x 4 | 8 | 32 in double: four 4 x 4 x 4 products per v_mfma_f64_4x4x4_4b_f64, elements straight from the planes, no LDS.
+//  * k_spmm_s4w    : 4 x 32 in float (4 x 4 | 8 without epilogue): k_spmm_small4's arithmetic with four neighbouring columns per lane (16-byte accesses).
 //  * k_spmm_small4 : the other 4-row shapes: one lane per element, operands once per thread group through LDS.
 //  * k_spmm_direct : one thread per output element; only as the epilogue of a user-defined operator,
 //    operands through the vector L1.
@@ -2234,6 +2235,159 @@ __global__ __launch_bounds__(256) void k_spmm_m4(SpmmArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 4 x 4 | 8 | 32 in float: k_spmm_small4's arithmetic (operands of a product once per thread group through a group-private LDS patch, a per-product
+// sum added to the block, k = 0..3 in order: bit-identical block products) with FOUR neighbouring columns per lane instead of one.  A lane of
+// k_spmm_small4 moves 4 bytes per memory instruction, 256 per wave, and these kernels are bound by the NUMBER of wave-wide memory instructions
+// (profiles/r04_four_row_shapes.txt): here X and every epilogue vector move as 16-byte accesses, a thread group is 4 | 8 | 16 lanes (row i, column quad),
+// a wave works on 16 | 8 | 4 block products at once.
+#ifndef TFQ_S4W_NB
+#define TFQ_S4W_NB 4
+#endif
+#ifndef TFQ_S4W_NBF
+#define TFQ_S4W_NBF 4
+#endif
+template <int LN, int EPI>
+__global__ __launch_bounds__(256) void k_spmm_s4w(SpmmArgs a) {
+    using R = float;
+    if (gate_closed(a)) return;
+    constexpr int LM = 4, P = LM * LN, W = 4;
+    constexpr int LNS = (LN > 16) ? 16 : LN;             // columns of a sub-block
+    constexpr int NSUB = LN / LNS;                       // sub-blocks per block (LN = 32: 2)
+    constexpr int QL = LNS / W;                          // column quads of a sub-block: 1, 2, 4
+    constexpr int PE = LM * QL;                          // lanes of a thread group: 4, 8, 16
+    constexpr int AV = (LM * LM) / PE;                   // elements of an A plane a lane fetches: 4, 2, 1
+    constexpr int NG = 256 / PE;                         // thread groups per work group
+    constexpr int NB = (EPI == EPI_NONE) ? TFQ_S4W_NB : TFQ_S4W_NBF;   // products whose operands are requested at once (the fused forms need their registers for the epilogue)
+    constexpr int NPL = EpiPlanes<EPI>::N;
+    static_assert(LN % LNS == 0 && LNS % W == 0 && NG % NSUB == 0, "a thread group keeps its sub-block index");
+    // (the patches of the 16 | 8 | 4 groups of a wave are read by one LDS instruction: strides of 128 | 256 | 512 bytes would put them all on the
+    //  same banks -- one pad of 16 bytes per column quad keeps the 16 segments of an instruction on 16 different bank quads)
+    constexpr int SA = 2 * LM * LM + 4, SX = 2 * LM * LNS + 4 * QL;
+    __shared__ __attribute__((aligned(16))) R AsF[NG * SA];
+    __shared__ __attribute__((aligned(16))) R XsF[NG * SX];
+    int const t = threadIdx.x, g = t / PE, e = t % PE;
+    int const i = e / QL, jq = e % QL;
+    int const j0 = (g % NSUB) * LNS + W * jq;            // first block column of this lane
+    R* const As = AsF + g * SA; R* const Xs = XsF + g * SX;   // this group's patches: [re | im] planes
+    uint32_t const chunk = a.order ? a.order[blockIdx.x] : blockIdx.x;   // XCD-aware launch order (tfq_plan.cpp)
+    uint32_t first, last, col = 0;
+    if (a.chunkFirst) { first = a.chunkFirst[chunk]; last = a.chunkFirst[chunk + 1]; col = a.chunkCol[chunk]; }
+    else { first = chunk * a.CH; last = min(first + a.CH, a.nY); }
+
+    R sr[W], si[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) { sr[w] = 0; si[w] = 0; }
+    if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            sr[w] = ((R const*)a.sc)[(size_t(col) * 2 + 0) * LN + j0 + w];
+            si[w] = ((R const*)a.sc)[(size_t(col) * 2 + 1) * LN + j0 + w];
+        }
+    }
+    double part[NPL > 0 ? NPL : 1][W] = {};
+
+    constexpr uint32_t kRows = 256, kPairs = 2048;       // the chunk's row ranges and index pairs in LDS, as k_spmm_small4
+    __shared__ uint32_t sStarts[kRows + 1];
+    __shared__ uint32_t sPairs[2 * kPairs];
+    uint32_t const nRows = last - first, nItems = nRows * NSUB;   // item = sub-block of a Y block; item % NSUB == g % NSUB
+    uint32_t const qBase = a.starts[first], qEnd = a.starts[last];
+    bool const inLds = (nRows <= kRows) && (qEnd - qBase <= kPairs);
+    if (inLds) {
+        for (uint32_t x = t; x <= nRows; x += 256) sStarts[x] = a.starts[first + x];
+        for (uint32_t x = t; x < 2 * (qEnd - qBase); x += 256) sPairs[x] = a.pairs[2 * size_t(qBase) + x];
+    }
+    __syncthreads();
+
+    struct Ops { R a[2][AV]; R x[2][W]; };
+    auto fetch = [&](Ops& o, uint32_t ia, uint32_t ix) __attribute__((always_inline)) {
+        R const* Ab = (R const*)a.A + size_t(ia) * 2 * (LM * LM) + AV * e;
+        R const* Xb = (R const*)a.X + size_t(ix) * 2 * P + i * LN + j0;
+        vload<R, AV>(o.a[0], Ab); vload<R, AV>(o.a[1], Ab + LM * LM);
+        vload<R, W>(o.x[0], Xb); vload<R, W>(o.x[1], Xb + P);
+    };
+    auto multiply = [&](Ops const& o, R (&yr)[W], R (&yi)[W]) __attribute__((always_inline)) {
+        __builtin_amdgcn_wave_barrier();                 // groups never straddle a wave, LDS operations of a wave complete in order
+        vstore<R, AV>(As + AV * e, o.a[0]); vstore<R, AV>(As + LM * LM + AV * e, o.a[1]);
+        vstore<R, W>(Xs + i * LNS + W * jq, o.x[0]); vstore<R, W>(Xs + LM * LNS + i * LNS + W * jq, o.x[1]);
+        __builtin_amdgcn_wave_barrier();
+        R cr[W], ci[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) { cr[w] = 0; ci[w] = 0; }
+#pragma unroll
+        for (int k = 0; k < LM; ++k) {
+            R const ar = As[k * LM + i], ai = As[LM * LM + k * LM + i];
+            R xr[W], xi[W];
+            vload<R, W>(xr, Xs + k * LNS + W * jq); vload<R, W>(xi, Xs + LM * LNS + k * LNS + W * jq);
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                cr[w] = fma_(-ai, xi[w], fma_(ar, xr[w], cr[w]));
+                ci[w] = fma_(ai, xr[w], fma_(ar, xi[w], ci[w]));
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < W; ++w) { yr[w] += cr[w]; yi[w] += ci[w]; }
+    };
+
+    for (uint32_t it = g; it < nItems; it += NG) {
+        uint32_t const kr = it / NSUB, y = first + kr;
+        int const eb = i * LN + j0;
+        size_t const off = size_t(y) * 2 * P + eb;
+        EpiOps<R, EPI, W> eo;
+        eo.load(a, off, P);
+        R yr[W], yi[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) { yr[w] = 0; yi[w] = 0; }
+        if (inLds) {
+            uint32_t const q0 = sStarts[kr] - qBase, q1 = sStarts[kr + 1] - qBase;
+            for (uint32_t qb = q0; qb < q1; qb += NB) {
+                Ops o[NB];
+                uint32_t ia[NB], ix[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {           // (unconditional, inside the patch: all NB reads in flight at once)
+                    uint32_t const qc = min(qb + u, kPairs - 1);
+                    ia[u] = sPairs[2 * qc]; ix[u] = sPairs[2 * qc + 1];
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) if (qb + u < q1) fetch(o[u], ia[u], ix[u]);
+#pragma unroll
+                for (int u = 0; u < NB; ++u) if (qb + u < q1) multiply(o[u], yr, yi);
+            }
+        } else {   // a chunk whose index data exceed the LDS patch: one product at a time, indices from global memory
+            for (uint32_t q = a.starts[y]; q < a.starts[y + 1]; ++q) {
+                Ops o;
+                fetch(o, a.pairs[2 * size_t(q)], a.pairs[2 * size_t(q) + 1]);
+                multiply(o, yr, yi);
+            }
+        }
+        uint32_t bq = 0xffffffffu;
+        if constexpr (EPI == EPI_RESIDUAL) bq = a.bOfX ? a.bOfX[y] : y;
+        epilogue_row<R, EPI, W, NPL, W>(a, off, P, yr, yi, sr, si, 0, eo, bq, eb, part, 0);
+    }
+
+    if constexpr (NPL > 0) {
+        // lanes that share a block column: the groups with the same sub-block index, 4 rows each; added in a fixed order
+        __shared__ double red[NPL][W][256];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int w = 0; w < W; ++w) red[p][w][t] = part[p][w];
+        __syncthreads();
+        for (int x = t; x < NPL * LN; x += 256) {
+            int const p = x / LN, jx = x % LN, jl = (jx % LNS) / W, jw = jx % W;
+            double sum = 0;
+#pragma unroll 1
+            for (int gg = jx / LNS; gg < NG; gg += NSUB)
+                for (int r = 0; r < LM; ++r) sum += red[p][jw][gg * PE + r * QL + jl];
+            write_record<EPI>(a, chunk, LN, p, jx, sum);
+        }
+        if (a.foldPlan) spmm_fold<R, LN, EPI>(a, col);   // small systems: the column operation behind this multiply, in the last work group of the column
+    }
+}
+
+// which 4-row shapes take k_spmm_s4w
+template <typename R, int LM, int LN> constexpr bool kSmall4w = (LM == 4 && sizeof(R) == 4 && LN % 4 == 0);
+
 // which 4-row shapes take k_spmm_m4
 template <typename R, int LM, int LN> constexpr bool kMfma4 = (LM == 4 && sizeof(R) == 8 && LN % 4 == 0);
 
@@ -2248,6 +2402,13 @@ template <typename R, int LM, int LN> constexpr bool kTile8 = (LM == 8) || (LM =
 template <typename R, int LM, int LN, int EPI>
 static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
     if (0 == nWG) return;
+    if constexpr (kSmall4w<R, LM, LN>) {   // (lab: TFQMRGPU_S4W=0 = k_spmm_small4, one column per lane; 2 = k_spmm_s4w for every launch of these shapes)
+        // the multiply without epilogue gains on all three shapes (4 x 4 | 8 | 32 c: 0.387 -> 0.276, 0.267 -> 0.218, 0.265 -> 0.178 ms); the fused forms hold the
+        // epilogue operands and double partial sums of four columns per lane (169 VGPRs: two waves per SIMD) and gain only where a block has many column
+        // quads: 4 x 32 (-21 %); 4 x 8 is level, 4 x 4 loses 13 % (profiles/r04_four_row_shapes.txt)
+        static int const use_s4w = lab_switch("TFQMRGPU_S4W", 1);
+        if (use_s4w && (EPI == EPI_NONE || LN == 32 || use_s4w > 1)) { k_spmm_s4w<LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a); return; }
+    }
     if constexpr (kMfma4<R, LM, LN>) {   // (lab: TFQMRGPU_M4=0 = the kernels these shapes had before, k_spmm_small4 and the half-empty tile of k_spmm_mfma8)
         static int const use_m4 = lab_switch("TFQMRGPU_M4", 1);
         if (use_m4) { k_spmm_m4<LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a); return; }
@@ -2463,6 +2624,7 @@ char const* spmm_kernel_family(DevPlan const& d) {
     if (LM % 16 == 0 && LN % 16 == 0) return "k_spmm_mfma";
     if (4 == LM && z && LN % 4 == 0 && lab_switch("TFQMRGPU_M4", 1)) return "k_spmm_m4";
     if (8 == LM || (4 == LM && z && 32 == LN)) return "k_spmm_mfma8";
+    if (4 == LM && !z && (32 == LN || (LN % 4 == 0 && lab_switch("TFQMRGPU_S4W", 1) > 1)) && lab_switch("TFQMRGPU_S4W", 1)) return "k_spmm_s4w";   // (the fused launches; 4 x 4 | 8 c take it without epilogue only)
     if (4 == LM) return "k_spmm_small4";
     return "k_spmm_direct";
 }
