@@ -1961,8 +1961,11 @@ __global__ __launch_bounds__(256) void k_spmm_small4(SpmmArgs a) {
     constexpr int NG = 4 * GPW;                          // thread groups per work group
     constexpr int NPL = EpiPlanes<EPI>::N;
     static_assert(LN % LNS == 0 && NG % NSUB == 0, "a thread group keeps its sub-block index");
-    __shared__ R As[NG][2][LM * LM];
-    __shared__ R Xs[NG][2][PE];
+    // (r04: the patches of a wave's groups are read by ONE LDS instruction; at their natural strides -- 128 | 256 bytes in float -- the groups' segments share
+    //  banks: padded by 16 bytes, as in k_spmm_s4w: 4 x 4 c iteration -2.7 %, 4 x 5 c -1 %; in double (4 x 5 z) a pad measured 0.4 % slower: none)
+    constexpr int PADR = (sizeof(R) == 4) ? 4 : 0;
+    __shared__ R As[NG][2 * LM * LM + PADR];
+    __shared__ R Xs[NG][2 * PE + PADR];
     int const t = threadIdx.x, wv = t >> 6, ln = t & 63;
     bool const valid = (ln < GPW * PE);
     int const g = wv * GPW + (valid ? ln / PE : GPW - 1), e = valid ? ln % PE : PE;   // idle lanes walk with the wave's last group and touch nothing
@@ -1998,14 +2001,14 @@ __global__ __launch_bounds__(256) void k_spmm_small4(SpmmArgs a) {
 
     auto multiply = [&](R const (&pa)[2], R const (&px)[2], R& yr, R& yi) __attribute__((always_inline)) {
         __builtin_amdgcn_wave_barrier();
-        if (e < LM * LM) { As[g][0][e] = pa[0]; As[g][1][e] = pa[1]; }
-        if (valid) { Xs[g][0][e] = px[0]; Xs[g][1][e] = px[1]; }
+        if (e < LM * LM) { As[g][e] = pa[0]; As[g][LM * LM + e] = pa[1]; }
+        if (valid) { Xs[g][e] = px[0]; Xs[g][PE + e] = px[1]; }
         __builtin_amdgcn_wave_barrier();
         R cr = 0, ci = 0;
 #pragma unroll
         for (int k = 0; k < LM; ++k) {
-            R const ar = As[g][0][k * LM + i], ai = As[g][1][k * LM + i];
-            R const xr = Xs[g][0][k * LNS + jj], xi = Xs[g][1][k * LNS + jj];
+            R const ar = As[g][k * LM + i], ai = As[g][LM * LM + k * LM + i];
+            R const xr = Xs[g][k * LNS + jj], xi = Xs[g][PE + k * LNS + jj];
             cr = fma_(-ai, xi, fma_(ar, xr, cr));
             ci = fma_(ai, xr, fma_(ar, xi, ci));
         }
