@@ -413,9 +413,9 @@ struct Slice {
 };
 
 // the vectors an epilogue reads, for the NT neighbouring elements of one lane in one row
-template <typename R, int EPI, int NT, bool HASH = false>
+template <typename R, int EPI, int NT, bool HASH = false, int STREAMSEL = -1>
 struct EpiOps {
-    static constexpr bool STREAM = (16 * NT * sizeof(R) >= 128);   // a lane group covers whole 128-byte lines
+    static constexpr bool STREAM = (STREAMSEL < 0) ? (16 * NT * sizeof(R) >= 128) : (STREAMSEL != 0);   // a lane group covers whole 128-byte lines (STREAMSEL: the kernel knows better)
     R ur[NT], ui[NT], xr[NT], xi[NT];
     float wr[NT], wi[NT];
     __device__ inline void load(SpmmArgs const& a, size_t off, int P) {
@@ -436,12 +436,12 @@ struct EpiOps {
 
 // epilogue for VW neighbouring elements at `off` (same arithmetic per element as epilogue<> above); the elements
 // are columns n0 .. n0 + VW - 1 of the NT columns of the lane (per-RHS scalars sr/si and partial sums are per column)
-template <typename R, int EPI, int VW, int NPL, int NT, bool HASH = false, int LN = 16>
+template <typename R, int EPI, int VW, int NPL, int NT, bool HASH = false, int LN = 16, typename OPS>
 __device__ inline void epilogue_row(SpmmArgs const& a, size_t off, int P, R const (&yr)[VW], R const (&yi)[VW],
-                                    R const (&sr)[NT], R const (&si)[NT], int n0, EpiOps<R, EPI, VW, HASH> const& o,
+                                    R const (&sr)[NT], R const (&si)[NT], int n0, OPS const& o,
                                     uint32_t bq, int eoff, double (&part)[NPL > 0 ? NPL : 1][NT], uint64_t key)
 {
-    if constexpr (EPI != EPI_RESIDUAL) { vstore_stream<EpiOps<R, EPI, VW, HASH>::STREAM, R, VW>((R*)a.Y + off, yr); vstore_stream<EpiOps<R, EPI, VW, HASH>::STREAM, R, VW>((R*)a.Y + off + P, yi); }
+    if constexpr (EPI != EPI_RESIDUAL) { vstore_stream<OPS::STREAM, R, VW>((R*)a.Y + off, yr); vstore_stream<OPS::STREAM, R, VW>((R*)a.Y + off + P, yi); }
     if constexpr (EPI == EPI_XPAY_DOT || EPI == EPI_AXPY_NRM_DOT) {
         R nr[VW], ni[VW];
 #pragma unroll
@@ -455,7 +455,7 @@ __device__ inline void epilogue_row(SpmmArgs const& a, size_t off, int P, R cons
             epi_dot(part[0][n0 + n], part[1][n0 + n], nr[n], ni[n], wr, wi);
             if constexpr (EPI == EPI_AXPY_NRM_DOT) epi_nrm(part[2][n0 + n], nr[n], ni[n]);
         }
-        vstore_stream<EpiOps<R, EPI, VW, HASH>::STREAM, R, VW>((R*)a.e0 + off, nr); vstore_stream<EpiOps<R, EPI, VW, HASH>::STREAM, R, VW>((R*)a.e0 + off + P, ni);
+        vstore_stream<OPS::STREAM, R, VW>((R*)a.e0 + off, nr); vstore_stream<OPS::STREAM, R, VW>((R*)a.e0 + off + P, ni);
     } else if constexpr (EPI == EPI_RESIDUAL) {
         R br[VW] = {}, bi[VW] = {};
         if (bq != 0xffffffffu) {
@@ -2336,7 +2336,7 @@ __global__ __launch_bounds__(256) void k_spmm_s4w(SpmmArgs a) {
         uint32_t const kr = it / NSUB, y = first + kr;
         int const eb = i * LN + j0;
         size_t const off = size_t(y) * 2 * P + eb;
-        EpiOps<R, EPI, W> eo;
+        EpiOps<R, EPI, W, false, (P * sizeof(R) >= 128) ? 1 : 0> eo;   // (4 x 4: a plane is 64 bytes, half a line -- no non-temporal accesses)
         eo.load(a, off, P);
         R yr[W], yi[W];
 #pragma unroll
