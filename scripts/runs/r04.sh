@@ -459,5 +459,17 @@ ay)
   done
   cat gpurun_out/r04ay_ab.txt
   ;;
+bh)
+  # vector kernels with cached instead of non-temporal accesses where a block plane is not a whole number of 128-byte lines: previous commit | tree  (net slower on 5 of 6 shapes: not in the tree)
+  step 900 r04bh_tests.log python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py tests/test_gpu_hash_mode.py -q
+  tail -n 3 gpurun_out/r04bh_tests.log
+  export AB_ALL=1
+  for wl in st:4:5:z:457:457:4 st:8:9:z:241:241:4 st:4:4:c:724:724:4 st:4:5:c:647:647:4 st:8:9:c:341:341:4 st:8:10:c:323:323:4 st:4:4:z:512:512:4; do
+    echo "## $wl" >> gpurun_out/r04bh_ab.txt
+    step 400 r04bh_one.txt python scripts/ab_fused.py $wl scripts/bin/libtfQMRgpu_prev.so default scripts/bin/libtfQMRgpu_prev.so default
+    grep -v amdgpu.ids gpurun_out/r04bh_one.txt | grep -v "^    " >> gpurun_out/r04bh_ab.txt
+  done
+  cat gpurun_out/r04bh_ab.txt
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac
