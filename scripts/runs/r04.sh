@@ -471,5 +471,14 @@ bh)
   done
   cat gpurun_out/r04bh_ab.txt
   ;;
+bi)
+  # soak of the new 4-row kernels (k_spmm_m4, k_spmm_small4 with its index data in LDS, k_spmm_s4w, k_spmm_mfma8 with scalar index loads): small (folded) and medium plans, z | c | m
+  for spec in "st:4:4:z:24:24:3 300" "st:4:8:z:64:64:4 200" "st:4:32:z:40:40:2 200" "st:4:5:z:64:64:3 200" "st:4:4:c:64:64:4 200" "st:4:32:c:40:40:2 200" "st:8:9:c:40:40:2 200" "st:4:8:z:24:24:3 200 m" "st:4:4:z:256:256:4 40"; do
+    set -- $spec
+    step 500 r04bi_one.txt python scripts/soak.py "$@"
+    tail -n 1 gpurun_out/r04bi_one.txt >> gpurun_out/r04bi_soak.txt
+  done
+  cat gpurun_out/r04bi_soak.txt
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac
