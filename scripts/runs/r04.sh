@@ -480,5 +480,17 @@ bi)
   done
   cat gpurun_out/r04bi_soak.txt
   ;;
+bj)
+  # k_spmm_m4 for LN = 4: neighbouring lanes share their memory instructions (even lane: the Re plane's two elements, odd lane: the Im plane's, one exchange): previous commit | tree  (slower: not in the tree)
+  step 900 r04bj_tests.log python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py tests/test_gpu_operator.py tests/test_gpu_mixed.py tests/test_gpu_hash_mode.py -q
+  tail -n 3 gpurun_out/r04bj_tests.log
+  export AB_ALL=1
+  for wl in st:4:4:z:512:512:4 st:4:4:z:512:512:4:13 st:4:4:z:24:24:3; do
+    echo "## $wl" >> gpurun_out/r04bj_ab.txt
+    step 400 r04bj_one.txt python scripts/ab_fused.py $wl scripts/bin/libtfQMRgpu_prev.so default scripts/bin/libtfQMRgpu_prev.so default
+    grep -v amdgpu.ids gpurun_out/r04bj_one.txt | grep -v "^    " >> gpurun_out/r04bj_ab.txt
+  done
+  cat gpurun_out/r04bj_ab.txt
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac
