@@ -2667,6 +2667,83 @@ void epilogue_launch(int epi, DevPlan const& d, void const* Yext, uint32_t const
 #undef TFQ_CASE
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 16 x 16 blocks on the CALLER's native planes (tfqmrgpuExt_multiply: the shape of the reference's `bench multi`, whose default precision is float).  In the native order a lane
+// of v_mfma_*_16x16x4 finds its operand element A[k][i] | X[k][j] 4 | 8 bytes at a time (k_spmm_mfma: 16 wave-wide loads of 256 | 512 bytes per block product, the
+// memory pipe's rate -- 0.28 | 0.45 of the matrix peak on the reference's plan file).  Here a wave fetches the four planes of a product as four 16-byte-per-lane accesses
+// (1 KiB each), passes them through a wave-private LDS patch and reads its operand elements from there (conflict-free: 64 consecutive floats per read).  The
+// k-steps and the order of the four real products are k_spmm_mfma's: bit-identical results.  The Y block leaves through the same patch as two 1-KiB stores.
+template <typename R>
+__global__ __launch_bounds__(256) void k_spmm_n16(SpmmArgs a) {
+    constexpr int P = 256;
+    constexpr int VE = 16 / sizeof(R);               // elements of a 16-byte access: 4 | 2
+    constexpr int NV = P / (64 * VE);                // accesses per lane and plane: 1 | 2
+    using V = R __attribute__((ext_vector_type(VE)));
+    using T4 = typename Acc<R>::T;
+    int const lane = threadIdx.x & 63;
+    int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int const lr = lane >> 4, lc = lane & 15;
+    using CU32 = __attribute__((address_space(4))) uint32_t const*;
+    CU32 const pairs = (CU32)(uintptr_t)a.pairs; CU32 const starts = (CU32)(uintptr_t)a.starts; CU32 const yOrder = (CU32)(uintptr_t)a.yOrder;
+    __shared__ __attribute__((aligned(16))) R patch[4][4 * P];   // per wave: A re | A im | X re | X im
+    R* const my = patch[wave];
+    uint32_t const chunk = a.plainPer ? (blockIdx.x & 7u) * a.plainPer + (blockIdx.x >> 3) : blockIdx.x;
+    uint32_t const pos = chunk * 4 + uint32_t(wave);              // (no barrier below: a wave without a Y block just leaves)
+    if (pos >= a.nY) return;
+    uint32_t const y = a.yOrder ? yOrder[pos] : pos;             // (a prepared order: which Y block this position computes)
+    uint32_t const q0 = starts[y], q1 = starts[y + 1];
+    T4 cre = T4{0, 0, 0, 0}, cim = T4{0, 0, 0, 0};
+    struct Ops { V v[4][NV]; };                      // [A re | A im | X re | X im][piece]: piece n of a plane = elements 64 VE n + VE lane ...
+    auto fetch = [&](Ops& o, uint32_t q) __attribute__((always_inline)) {
+        R const* Ab = (R const*)a.A + size_t(pairs[2 * size_t(q)]) * 2 * P + VE * lane;
+        R const* Xb = (R const*)a.X + size_t(pairs[2 * size_t(q) + 1]) * 2 * P + VE * lane;
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            o.v[0][n] = *(V const*)(Ab + 64 * VE * n); o.v[1][n] = *(V const*)(Ab + P + 64 * VE * n);
+            o.v[2][n] = *(V const*)(Xb + 64 * VE * n); o.v[3][n] = *(V const*)(Xb + P + 64 * VE * n);
+        }
+    };
+    auto mma = [&](Ops const& o) __attribute__((always_inline)) {
+        __builtin_amdgcn_wave_barrier();             // LDS operations of one wave complete in order: the patch is free when these writes execute
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl)
+#pragma unroll
+            for (int n = 0; n < NV; ++n) *(V*)(my + pl * P + 64 * VE * n + VE * lane) = o.v[pl][n];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                // k = 4 s + lr: lane (lr, lc) feeds A[k][i = lc] and X[k][j = lc]
+            int const e = (4 * s + lr) * 16 + lc;
+            R const ar = my[e], ai = my[P + e], xr = my[2 * P + e], xi = my[3 * P + e];
+            cre = Acc<R>::mma(ar, xr, cre);
+            cim = Acc<R>::mma(ar, xi, cim);
+            cre = Acc<R>::mma(-ai, xi, cre);
+            cim = Acc<R>::mma(ai, xr, cim);
+        }
+    };
+    Ops o0, o1;
+    if (q0 < q1) fetch(o0, q0);
+    if (q0 + 1 < q1) fetch(o1, q0 + 1);
+    uint32_t q = q0;
+    for (; q + 2 <= q1; q += 2) {
+        mma(o0);
+        if (q + 2 < q1) fetch(o0, q + 2);
+        mma(o1);
+        if (q + 3 < q1) fetch(o1, q + 3);
+    }
+    if (q < q1) mma(o0);
+    // the accumulator registers of a lane are rows Acc<R>::row(lane, r) of column lc: through the patch into 16 bytes per lane
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { my[Acc<R>::row(lane, r) * 16 + lc] = cre[r]; my[P + Acc<R>::row(lane, r) * 16 + lc] = cim[r]; }
+    __builtin_amdgcn_wave_barrier();
+    R* const Yb = (R*)a.Y + size_t(y) * 2 * P + VE * lane;
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        *(V*)(Yb + 64 * VE * n) = *(V const*)(my + 64 * VE * n + VE * lane);
+        *(V*)(Yb + P + 64 * VE * n) = *(V const*)(my + P + 64 * VE * n + VE * lane);
+    }
+}
+
 uint32_t multiply_blocks_per_work_group(char precision, int lm, int ln) {
     bool const dbl = ('z' == (precision | 32)) || ('d' == (precision | 32));
     bool const mfma = (lm % 16 == 0 && ln % 16 == 0);
@@ -2698,6 +2775,12 @@ tfqmrgpuStatus_t launch_multiply(char precision, int lm, int ln, uint32_t nnzbY,
     uint32_t nWG = (nnzbY + ch - 1) / ch;
     // (lab: contiguous eighths of the caller's Y blocks per XCD instead of round-robin work groups)
     if (mfma && nWG >= 64 && lab_switch("TFQMRGPU_PLAIN_XCD", 0)) { a.plainPer = (nWG + 7) / 8; nWG = 8 * a.plainPer; }
+    // float: the reference's plan file 44.3 -> 59.2 TFLOP/s (0.28 -> 0.38 of the matrix peak), a 16 x 16 c stencil 0.360 -> 0.249 ms (0.55); double: the LDS traffic doubles with the
+    // element size and the plan file LOSES 7 % (35.3 -> 32.9), P2 gains 3 %: float only (lab: TFQMRGPU_N16 bit 0 = float, bit 1 = double; profiles/r04_native_multiply.txt)
+    if (16 == lm && 16 == ln && (lab_switch("TFQMRGPU_N16", 1) & (dbl ? 2 : 1))) {
+        if (nWG) { if (dbl) k_spmm_n16<double><<<dim3(nWG), dim3(256), 0, s>>>(a); else k_spmm_n16<float><<<dim3(nWG), dim3(256), 0, s>>>(a); }
+        return (hipSuccess == hipGetLastError()) ? TFQMRGPU_STATUS_SUCCESS : TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
+    }
     if (!spmm_dispatch(dbl, lm, ln, EPI_NONE, a, nWG, s))
         return err(TFQMRGPU_BLOCKSIZE_MISSING, ln, lm);
     return (hipSuccess == hipGetLastError()) ? TFQMRGPU_STATUS_SUCCESS : TFQ_ERR(TFQMRGPU_STATUS_LAUNCH_FAILED);
