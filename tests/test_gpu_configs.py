@@ -144,7 +144,7 @@ def test_config5_one_gpu(torch_cuda, oracle):
                                                ((12, 12, 32, 32, 2), "c", "k_spmm_ilvf"), ((12, 12, 32, 32, 2), "z", "k_spmm_mfma"),
                                                ((20, 20, 8, 32, 2), "z", "k_spmm_ilv8w"), ((20, 20, 8, 9, 2), "z", "k_spmm_ilv8w"), ((20, 20, 8, 9, 2), "c", "k_spmm_mfma8"),
                                                ((30, 30, 4, 5, 2), "z", "k_spmm_small4"), ((30, 30, 4, 4, 2), "z", "k_spmm_m4"), ((30, 30, 4, 8, 2), "z", "k_spmm_m4"),
-                                               ((20, 20, 4, 32, 2), "z", "k_spmm_m4"), ((30, 30, 4, 8, 2), "c", "k_spmm_small4"), ((20, 20, 4, 32, 2), "c", "k_spmm_s4w"), ((30, 30, 4, 5, 2), "c", "k_spmm_small4")])
+                                               ((20, 20, 4, 32, 2), "z", "k_spmm_m4"), ((30, 30, 4, 8, 2), "c", "k_spmm_s4w"), ((20, 20, 4, 32, 2), "c", "k_spmm_s4w"), ((30, 30, 4, 4, 2), "c", "k_spmm_small4"), ((30, 30, 4, 5, 2), "c", "k_spmm_small4")])
 def test_the_library_names_the_kernel_family_of_a_plan(shape, prec, family):
     """tfqmrgpuExt_getMultiplyKernel: what bench.py holds the kept profiler figures of profiles/pmc_traffic.json against (a traffic
     figure of a kernel that no longer runs must not be quoted)"""

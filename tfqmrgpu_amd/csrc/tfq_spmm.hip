@@ -24,7 +24,7 @@
 //  * k_spmm_mfma8 : LM == 8 (and 4 x 32 z): [Re A; Im A] x [Re X | Im X] fills one 16 x 16 tile per 8 block columns (LN = 9,
 //    10: the last tile is masked; LM == 4: half of the rows are empty -- the matrix pipe is idle in these HBM-bound shapes).
 //  * k_spmm_m4     : 4 x 4 | 8 | 32 in double: four 4 x 4 x 4 products per v_mfma_f64_4x4x4_4b_f64, elements straight from the planes, no LDS.
-//  * k_spmm_s4w    : 4 x 32 in float (4 x 4 | 8 without epilogue): k_spmm_small4's arithmetic with four neighbouring columns per lane (16-byte accesses).
+//  * k_spmm_s4w    : 4 x 8 | 32 in float (4 x 4 without epilogue): k_spmm_small4's arithmetic with two | four neighbouring columns per lane.
 //  * k_spmm_small4 : the other 4-row shapes: one lane per element, operands once per thread group through LDS.
 //  * k_spmm_direct : one thread per output element; only as the epilogue of a user-defined operator,
 //    operands through the vector L1.
@@ -2250,11 +2250,11 @@ __global__ __launch_bounds__(256) void k_spmm_m4(SpmmArgs a) {
 #ifndef TFQ_S4W_NBF
 #define TFQ_S4W_NBF 4
 #endif
-template <int LN, int EPI>
+template <int LN, int EPI, int W = 4>   // W: neighbouring columns of a lane, 4 (16-byte accesses) or 2
 __global__ __launch_bounds__(256) void k_spmm_s4w(SpmmArgs a) {
     using R = float;
     if (gate_closed(a)) return;
-    constexpr int LM = 4, P = LM * LN, W = 4;
+    constexpr int LM = 4, P = LM * LN;
     constexpr int LNS = (LN > 16) ? 16 : LN;             // columns of a sub-block
     constexpr int NSUB = LN / LNS;                       // sub-blocks per block (LN = 32: 2)
     constexpr int QL = LNS / W;                          // column quads of a sub-block: 1, 2, 4
@@ -2266,7 +2266,7 @@ __global__ __launch_bounds__(256) void k_spmm_s4w(SpmmArgs a) {
     static_assert(LN % LNS == 0 && LNS % W == 0 && NG % NSUB == 0, "a thread group keeps its sub-block index");
     // (the patches of the 16 | 8 | 4 groups of a wave are read by one LDS instruction: strides of 128 | 256 | 512 bytes would put them all on the
     //  same banks -- one pad of 16 bytes per column quad keeps the 16 segments of an instruction on 16 different bank quads)
-    constexpr int SA = 2 * LM * LM + 4, SX = 2 * LM * LNS + 4 * QL;
+    constexpr int SA = 2 * LM * LM + 4, SX = 2 * LM * LNS + 4 * ((QL * W) / 4);
     __shared__ __attribute__((aligned(16))) R AsF[NG * SA];
     __shared__ __attribute__((aligned(16))) R XsF[NG * SX];
     int const t = threadIdx.x, g = t / PE, e = t % PE;
@@ -2410,7 +2410,10 @@ static void spmm_go(SpmmArgs const& a, uint32_t nWG, hipStream_t s) {
         // epilogue operands and double partial sums of four columns per lane (169 VGPRs: two waves per SIMD) and gain only where a block has many column
         // quads: 4 x 32 (-21 %); 4 x 8 is level, 4 x 4 loses 13 % (profiles/r04_four_row_shapes.txt)
         static int const use_s4w = lab_switch("TFQMRGPU_S4W", 1);
-        if (use_s4w && (EPI == EPI_NONE || LN == 32 || use_s4w > 1)) { k_spmm_s4w<LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a); return; }
+        if (use_s4w && (EPI == EPI_NONE || LN == 32 || use_s4w == 2)) { k_spmm_s4w<LN, EPI><<<dim3(nWG), dim3(256), 0, s>>>(a); return; }
+        // the fused launches of 4 x 8 with TWO columns per lane (129 VGPRs): 0.472 / 0.434 -> 0.419 / 0.392 ms, iteration 1.497 -> 1.398; 4 x 4 stays with k_spmm_small4 (two
+        // columns per lane: 1.652 -> 1.684).  (lab: 3 = two columns per lane for both)
+        if constexpr (LN < 32) if ((use_s4w == 1 && LN == 8) || use_s4w == 3) { k_spmm_s4w<LN, EPI, 2><<<dim3(nWG), dim3(256), 0, s>>>(a); return; }
     }
     if constexpr (kMfma4<R, LM, LN>) {   // (lab: TFQMRGPU_M4=0 = the kernels these shapes had before, k_spmm_small4 and the half-empty tile of k_spmm_mfma8)
         static int const use_m4 = lab_switch("TFQMRGPU_M4", 1);
@@ -2627,7 +2630,7 @@ char const* spmm_kernel_family(DevPlan const& d) {
     if (LM % 16 == 0 && LN % 16 == 0) return "k_spmm_mfma";
     if (4 == LM && z && LN % 4 == 0 && lab_switch("TFQMRGPU_M4", 1)) return "k_spmm_m4";
     if (8 == LM || (4 == LM && z && 32 == LN)) return "k_spmm_mfma8";
-    if (4 == LM && !z && (32 == LN || (LN % 4 == 0 && lab_switch("TFQMRGPU_S4W", 1) > 1)) && lab_switch("TFQMRGPU_S4W", 1)) return "k_spmm_s4w";   // (the fused launches; 4 x 4 | 8 c take it without epilogue only)
+    if (4 == LM && !z && (32 == LN || 8 == LN || (4 == LN && lab_switch("TFQMRGPU_S4W", 1) > 1)) && lab_switch("TFQMRGPU_S4W", 1)) return "k_spmm_s4w";   // (the fused launches; 4 x 4 c takes it without epilogue only)
     if (4 == LM) return "k_spmm_small4";
     return "k_spmm_direct";
 }
