@@ -492,5 +492,17 @@ bj)
   done
   cat gpurun_out/r04bj_ab.txt
   ;;
+br)
+  # 8 x 9 and 8 x 10 c on the quad-interleaved order (k_spmm_ilv8f with a ragged second column group) against k_spmm_mfma8 on the native order: lab switch TFQMRGPU_ILV89F = 0 | 1  (fused multiplies slower: not in the tree)
+  step 900 r04br_tests.log python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py tests/test_gpu_operator.py tests/test_gpu_mixed.py tests/test_gpu_hash_mode.py -q
+  tail -n 3 gpurun_out/r04br_tests.log
+  export AB_ALL=1
+  for wl in st:8:9:c:341:341:4 st:8:10:c:323:323:4; do
+    echo "## $wl" >> gpurun_out/r04br_ab.txt
+    step 400 r04br_one.txt python scripts/ab_fused.py $wl lab@TFQMRGPU_ILV89F=0 lab@TFQMRGPU_ILV89F=1 lab@TFQMRGPU_ILV89F=0 lab@TFQMRGPU_ILV89F=1
+    grep -v amdgpu.ids gpurun_out/r04br_one.txt | grep -v "^    " >> gpurun_out/r04br_ab.txt
+  done
+  cat gpurun_out/r04br_ab.txt
+  ;;
 *) echo "unknown step $1"; exit 1;;
 esac
