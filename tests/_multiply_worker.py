@@ -1,5 +1,5 @@
 """Worker of tests/test_gpu_hash_mode.py::test_plain_mode_xcd_mapping: the reference's plan file (BASELINE config 1) through the native-API multiply
-in a fresh process, product written to argv[1].  With TFQMRGPU_* switches in the environment the LAB build is loaded (as tests/_env_worker.py)."""
+in a fresh process, product written to argv[1]; argv[2] (optional): precision z | c.  With TFQMRGPU_* switches in the environment the LAB build is loaded (as tests/_env_worker.py)."""
 import os
 import sys
 
@@ -11,6 +11,8 @@ sys.path.insert(0, ROOT)
 
 def main():
     out = sys.argv[1]
+    prec = sys.argv[2] if len(sys.argv) > 2 else "z"
+    real = np.float64 if prec == "z" else np.float32
     import torch
     assert torch.cuda.is_available(), "no GPU: the product has no CPU fallback"
     switches = [k for k in os.environ if k.startswith("TFQMRGPU_") and k != "TFQMRGPU_LIB"]
@@ -26,14 +28,14 @@ def main():
     assert len(starts) == nY + 1
     pairs = np.ascontiguousarray(rows[:, 1:3].reshape(-1).astype(np.int32))
     rng = np.random.default_rng(5)
-    A = rng.uniform(-1, 1, (nA, 2, 16, 16))
-    X = rng.uniform(-1, 1, (nX, 2, 16, 16))
+    A = rng.uniform(-1, 1, (nA, 2, 16, 16)).astype(real)
+    X = rng.uniform(-1, 1, (nX, 2, 16, 16)).astype(real)
     _dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     with T.Solver() as s:
         dA, dX = _dev(A), _dev(X)
-        dY = torch.zeros((nY, 2, 16, 16), dtype=torch.float64, device="cuda")
+        dY = torch.zeros((nY, 2, 16, 16), dtype=torch.float64 if prec == "z" else torch.float32, device="cuda")
         dS, dP = _dev(starts), _dev(pairs)
-        assert T.lib.tfqmrgpuExt_multiply(s.handle, b"z", 16, 16, nY, dS.data_ptr(), dP.data_ptr(), dA.data_ptr(), dX.data_ptr(), dY.data_ptr()) == 0
+        assert T.lib.tfqmrgpuExt_multiply(s.handle, prec.encode(), 16, 16, nY, dS.data_ptr(), dP.data_ptr(), dA.data_ptr(), dX.data_ptr(), dY.data_ptr()) == 0
         torch.cuda.synchronize()
         np.savez(out, Y=dY.cpu().numpy(), lib=os.path.basename(T.LIB_PATH))
 

@@ -206,6 +206,24 @@ def test_plain_mode_xcd_mapping(tmp_path):
     assert np.array_equal(got["product"]["Y"], got["lab"]["Y"]) and np.array_equal(got["product"]["Y"], got["eighths"]["Y"])
 
 
+def test_native_16x16_multiply_through_the_lds_patch_changes_no_bit(tmp_path):
+    """k_spmm_n16 (r04: the stand-alone 16 x 16 multiply on the caller's planes with its operands through a wave-private LDS patch as 16-byte accesses; float ships,
+    double is a lab option) against k_spmm_mfma (4 | 8-byte operand loads, lab switch TFQMRGPU_N16=0): same k-steps, same order of the four real products --
+    not a bit of the product on BASELINE config 1's plan may differ, in either precision."""
+    def run(tag, prec, **env):
+        out = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_multiply_worker.py"), out, prec],
+                           env=dict(os.environ, **{k: str(v) for k, v in env.items()}), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        return np.load(out)
+    c_product, c_direct, c_patch = run("c_product", "c"), run("c_direct", "c", TFQMRGPU_N16=0), run("c_patch", "c", TFQMRGPU_N16=1)
+    assert str(c_product["lib"]) == "libtfQMRgpu.so" and str(c_direct["lib"]) == "libtfQMRgpu_lab.so"
+    assert np.abs(c_product["Y"]).max() > 1 and c_product["Y"].dtype == np.float32
+    assert np.array_equal(c_product["Y"], c_direct["Y"]) and np.array_equal(c_product["Y"], c_patch["Y"])
+    z_direct, z_patch = run("z_direct", "z", TFQMRGPU_N16=0), run("z_patch", "z", TFQMRGPU_N16=3)
+    assert np.array_equal(z_direct["Y"], z_patch["Y"])
+
+
 # ---- kernel-level state parity (SURVEY 8 a8-a10: axpy/xpay, dotp/nrm2, dec35/dec34/decT) ----------------------------
 # After exactly k iterations every work vector is the output of one kernel of the slot (x, v6, v7: k_x_v6_v7; v4, v9:
 # the EPI_XPAY_DOT multiply; v5, v8: the EPI_AXPY_NRM_DOT multiply and k_v5_nrm), computed with the per-RHS scalars of
