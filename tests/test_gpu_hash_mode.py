@@ -206,6 +206,21 @@ def test_plain_mode_xcd_mapping(tmp_path):
     assert np.array_equal(got["product"]["Y"], got["lab"]["Y"]) and np.array_equal(got["product"]["Y"], got["eighths"]["Y"])
 
 
+@pytest.mark.parametrize("name,prec,tol,switch,xtol", [
+    ("stencil:40:40:4:4:3:5:5", "z", 1e-9, dict(TFQMRGPU_M4=0), 1e-9), ("stencil:40:40:4:8:3:5:5", "z", 1e-9, dict(TFQMRGPU_M4=0), 1e-9),
+    ("stencil:24:24:4:32:2:5:5", "z", 1e-9, dict(TFQMRGPU_M4=0), 1e-9),       # k_spmm_m4 against k_spmm_small4 | the tile of k_spmm_mfma8 (one running sum per Y block)
+    ("stencil:40:40:4:8:3:5:5", "c", 1e-4, dict(TFQMRGPU_S4W=0), 2e-4), ("stencil:24:24:4:32:2:5:5", "c", 1e-4, dict(TFQMRGPU_S4W=0), 2e-4),   # k_spmm_s4w against k_spmm_small4
+    ("stencil:40:40:4:4:3:5:5", "c", 1e-4, dict(TFQMRGPU_S4W=2), 2e-4)])      # ... and fused on 4 x 4 c, where the product keeps k_spmm_small4
+def test_four_row_kernels_against_the_kernels_they_replaced(tmp_path, name, prec, tol, switch, xtol):
+    """r04: the 4-row shapes moved to new multiply kernels; the ones they replaced stay reachable in the lab build (TFQMRGPU_M4=0, TFQMRGPU_S4W=0): same status and
+    iteration count, the solution within rounding (the sums of a chunk's records are grouped differently; k_spmm_m4 adds the products of a Y block in one running sum)"""
+    new = _worker(tmp_path, "new", name, prec, tol)
+    old = _worker(tmp_path, "old", name, prec, tol, **switch)
+    assert int(new["status"]) == int(old["status"]) == 0 and int(new["iterations"]) == int(old["iterations"])
+    assert np.allclose(new["history"][: (len(new["history"]) + 1) // 2], old["history"][: (len(old["history"]) + 1) // 2], rtol=1e-6 if prec == "z" else 2e-2, atol=0)
+    assert np.abs(new["X"] - old["X"]).max() <= xtol * np.abs(old["X"]).max()
+
+
 def test_native_16x16_multiply_through_the_lds_patch_changes_no_bit(tmp_path):
     """k_spmm_n16 (r04: the stand-alone 16 x 16 multiply on the caller's planes with its operands through a wave-private LDS patch as 16-byte accesses; float ships,
     double is a lab option) against k_spmm_mfma (4 | 8-byte operand loads, lab switch TFQMRGPU_N16=0): same k-steps, same order of the four real products --
